@@ -1,0 +1,114 @@
+"""ctypes binding of libdsvc.so (the C ABI declared in include/dsvc.h).
+
+There is NO fallback: if the library is missing this module raises, and every op in
+`deepsvc_amd.ops` goes through it.  Build with `python -m deepsvc_amd.build`.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdsvc.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_HALF_TANH = range(6)
+EW_COPY, EW_ADD, EW_SUB, EW_BLEND2, EW_BLEND3, EW_CLAMP01 = range(6)
+EB_PARAMS_PER_CH = 59
+
+
+class Seg(Structure):
+    _fields_ = [("ptr", c_void_p), ("C", c_int32), ("ld", c_int32), ("dtype", c_int32)]
+
+
+class ConvDesc(Structure):
+    _fields_ = [
+        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("nseg", c_int32),
+        ("seg", Seg * 3),
+        ("kh", c_int32), ("kw", c_int32), ("stride", c_int32), ("pad", c_int32),
+        ("Cout", c_int32), ("compute", c_int32),
+        ("weight", c_void_p), ("bias", c_void_p),
+        ("pre_act", c_int32), ("act", c_int32), ("slope", c_float),
+        ("res1", c_void_p), ("res1_ld", c_int32), ("res1_dtype", c_int32),
+        ("res1_scale", c_void_p),
+        ("res2", c_void_p), ("res2_ld", c_int32), ("res2_dtype", c_int32),
+        ("shuffle", c_int32),
+        ("out", c_void_p), ("out_ld", c_int32), ("out_dtype", c_int32),
+    ]
+
+
+class Operand(Structure):
+    _fields_ = [("ptr", c_void_p), ("ld", c_int32), ("dtype", c_int32)]
+
+
+class CdfTable(Structure):
+    _fields_ = [("cdf", c_void_p), ("rows", c_int32), ("stride", c_int32), ("cdf_length", c_void_p), ("offset", c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol of include/dsvc.h is listed (tests check this against the header)
+SIGNATURES = {
+    "dsvc_last_error": (c_char_p, []),
+    "dsvc_version": (c_int, []),
+    "dsvc_device_count": (c_int, []),
+    "dsvc_conv_packed_bytes": (c_int64, [c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32]),
+    "dsvc_conv_pack_weights": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
+    "dsvc_deconv5x5s2_to_conv3x3": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "dsvc_conv2d": (c_int, [c_void_p, POINTER(ConvDesc)]),
+    "dsvc_warp_bilinear_border": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                          c_int32, c_int32, c_int32, c_int32]),
+    "dsvc_upsample2x_bilinear": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float]),
+    "dsvc_pool2x2": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "dsvc_pixel_shuffle_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "dsvc_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "dsvc_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32]),
+    "dsvc_eltwise": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(Operand), POINTER(Operand), POINTER(Operand),
+                             POINTER(Operand), POINTER(Operand), c_void_p, c_int32, c_int32]),
+    "dsvc_se_workspace_floats": (c_int64, [c_int32, c_int32]),
+    "dsvc_se_gate": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                             c_void_p, c_void_p]),
+    "dsvc_reduce_workspace_floats": (c_int64, []),
+    "dsvc_reduce": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(Operand), POINTER(Operand), c_void_p, c_void_p]),
+    "dsvc_gc_quantize": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32,
+                                 c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32]),
+    "dsvc_gc_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32]),
+    "dsvc_gc_likelihood": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int64, c_int32,
+                                   c_void_p, c_int32, c_void_p, c_int32]),
+    "dsvc_eb_process": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
+    "dsvc_eb_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32]),
+    "dsvc_pmf_to_quantized_cdf": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    "dsvc_rans_encoder_create": (c_int, [POINTER(c_void_p)]),
+    "dsvc_rans_encoder_destroy": (None, [c_void_p]),
+    "dsvc_rans_encode_with_indexes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(CdfTable)]),
+    "dsvc_rans_flush": (c_int64, [c_void_p, c_void_p, c_int64]),
+    "dsvc_rans_decoder_create": (c_int, [POINTER(c_void_p), c_char_p, c_int64]),
+    "dsvc_rans_decoder_destroy": (None, [c_void_p]),
+    "dsvc_rans_decode_stream": (c_int, [c_void_p, c_void_p, c_int64, POINTER(CdfTable), c_void_p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} is missing: build it with `python -m deepsvc_amd.build` "
+                              "(the HIP extension is mandatory; there is no fallback path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc is not None and rc < 0:
+        msg = lib().dsvc_last_error()
+        raise NativeError(f"{what} failed (rc={rc}): {msg.decode(errors='replace') if msg else ''}")
+    return rc

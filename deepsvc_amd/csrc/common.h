@@ -1,0 +1,55 @@
+// Shared host/device helpers of libdsvc (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dsvc.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// ---- error plumbing (api.cpp) ----------------------------------------------------------------
+void dsvc_set_error(const char* fmt, ...);
+#define DSVC_REQUIRE(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            dsvc_set_error(__VA_ARGS__);                \
+            return DSVC_E_ARG;                          \
+        }                                               \
+    } while (0)
+#define DSVC_CHECK_LAUNCH(what)                                                          \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            dsvc_set_error("%s: %s", what, hipGetErrorString(e_));                       \
+            return DSVC_E_LAUNCH;                                                        \
+        }                                                                                \
+    } while (0)
+
+// ---- element access with runtime storage type ------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __builtin_bit_cast(float, (unsigned int)b << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+}
+__device__ __forceinline__ float load_elem(const void* p, int dtype, int64_t i) {
+    return dtype == DSVC_F32 ? ((const float*)p)[i] : bf16_bits_to_f32(((const unsigned short*)p)[i]);
+}
+__device__ __forceinline__ void store_elem(void* p, int dtype, int64_t i, float v) {
+    if (dtype == DSVC_F32) ((float*)p)[i] = v;
+    else ((unsigned short*)p)[i] = f32_to_bf16_bits(v);
+}
+static inline int dsvc_esize(int dtype) { return dtype == DSVC_F32 ? 4 : 2; }
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case DSVC_ACT_RELU: return v > 0.f ? v : 0.f;
+        case DSVC_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case DSVC_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case DSVC_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case DSVC_ACT_HALF_TANH: return 0.5f * tanhf(v);
+        default: return v;
+    }
+}

@@ -1,0 +1,122 @@
+// host_misc.cpp -- host-side helpers of libdsvc: error plumbing, integer CDF construction,
+// weight repacking for the MFMA conv kernel, transposed-conv -> sub-pixel conv rewrite.
+#include <cstdarg>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void dsvc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dsvc_last_error(void) { return g_err; }
+extern "C" int dsvc_version(void) { return DSVC_VERSION; }
+
+extern "C" int dsvc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// compressai _CXX.pmf_to_quantized_cdf (ported there from ryg_rans) -- SURVEY.md Appendix A.4;
+// reached from the reference through update(): image_model.py:319-324, video_model.py:179-182.
+extern "C" int dsvc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf_out) {
+    DSVC_REQUIRE(pmf && cdf_out && n > 0 && precision > 0 && precision <= 16, "pmf_to_quantized_cdf: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!(pmf[i] >= 0.f) || !std::isfinite(pmf[i])) { dsvc_set_error("pmf_to_quantized_cdf: invalid pmf[%d]", i); return DSVC_E_PMF; }
+    std::vector<uint32_t> c((size_t)n + 1);
+    c[0] = 0;
+    uint32_t total = 0;
+    for (int i = 0; i < n; ++i) { c[i + 1] = (uint32_t)std::round(pmf[i] * (float)(1 << precision)); total += c[i + 1]; }
+    if (total == 0) { dsvc_set_error("pmf_to_quantized_cdf: pmf sums to zero"); return DSVC_E_PMF; }
+    uint32_t run = 0;
+    for (int i = 0; i <= n; ++i) { run += (uint32_t)((((uint64_t)1 << precision) * c[i]) / total); c[i] = run; }
+    c[n] = 1u << precision;
+    for (int i = 0; i < n; ++i) {
+        if (c[i] != c[i + 1]) continue;
+        uint32_t best_freq = ~0u; int best = -1;   // steal from the rarest symbol that can spare one count
+        for (int j = 0; j < n; ++j) {
+            const uint32_t f = c[j + 1] - c[j];
+            if (f > 1 && f < best_freq) { best_freq = f; best = j; }
+        }
+        if (best < 0) { dsvc_set_error("pmf_to_quantized_cdf: cannot make bin %d non-empty", i); return DSVC_E_PMF; }
+        if (best < i) { for (int j = best + 1; j <= i; ++j) c[j]--; }
+        else { for (int j = i + 1; j <= best; ++j) c[j]++; }
+    }
+    for (int i = 0; i <= n; ++i) cdf_out[i] = (int32_t)c[i];
+    return DSVC_OK;
+}
+
+static inline uint16_t f32_to_bf16_host(float f) {  // round to nearest even; NaN stays NaN
+    uint32_t u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// OIHW fp32 -> [chunk][tap][Np][64 B] of the compute type; chunks never straddle input segments.
+extern "C" int dsvc_conv_pack_weights(const float* w, int32_t Cout, int32_t nseg, const int32_t* segC,
+                                      int32_t kh, int32_t kw, int32_t compute, void* packed) {
+    DSVC_REQUIRE(w && packed && segC, "conv_pack_weights: null argument");
+    DSVC_REQUIRE(Cout > 0 && nseg >= 1 && nseg <= 3 && kh >= 1 && kw >= 1, "conv_pack_weights: bad shape");
+    DSVC_REQUIRE(compute == DSVC_F32 || compute == DSVC_BF16, "conv_pack_weights: bad compute type");
+    const int kce = compute == DSVC_F32 ? 16 : 32;
+    const int64_t Np = (Cout + 31) / 32 * 32;
+    const int taps = kh * kw;
+    int Cin = 0;
+    for (int s = 0; s < nseg; ++s) { DSVC_REQUIRE(segC[s] > 0, "conv_pack_weights: empty segment"); Cin += segC[s]; }
+    const int64_t total = dsvc_conv_packed_bytes(Cout, nseg, segC, kh, kw, compute);
+    std::memset(packed, 0, (size_t)total);
+    int64_t chunk = 0;
+    int cbase = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int nch = (segC[s] + kce - 1) / kce;
+        for (int j = 0; j < nch; ++j, ++chunk) {
+            for (int t = 0; t < taps; ++t) {
+                for (int n = 0; n < Cout; ++n) {
+                    char* row = (char*)packed + ((chunk * taps + t) * Np + n) * 64;
+                    for (int e = 0; e < kce; ++e) {
+                        const int cl = j * kce + e;
+                        if (cl >= segC[s]) break;
+                        const float v = w[((int64_t)n * Cin + (cbase + cl)) * taps + t];
+                        if (compute == DSVC_F32) ((float*)row)[e] = v;
+                        else ((uint16_t*)row)[e] = f32_to_bf16_host(v);
+                    }
+                }
+            }
+        }
+        cbase += segC[s];
+    }
+    return DSVC_OK;
+}
+
+// ConvTranspose2d(k5,s2,p2,op1): out[2Y+py][2X+px] = sum_{dy,dx in {-1,0,1}} in[Y+dy][X+dx] * Wt[py+2-2dy][px+2-2dx]
+// (taps outside 0..4 vanish) -> a 3x3 pad-1 conv producing 4 phase channels per output channel.
+extern "C" int dsvc_deconv5x5s2_to_conv3x3(const float* wt, const float* bias, int32_t Cin, int32_t Cout,
+                                           float* wo, float* bias4) {
+    DSVC_REQUIRE(wt && wo && Cin > 0 && Cout > 0, "deconv_to_conv: bad argument");
+    std::memset(wo, 0, sizeof(float) * (size_t)4 * Cout * Cin * 9);
+    for (int co = 0; co < Cout; ++co)
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int o = co * 4 + py * 2 + px;
+                if (bias4) bias4[o] = bias ? bias[co] : 0.f;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int ky = py + 2 - 2 * dy;
+                    if (ky < 0 || ky > 4) continue;
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int kx = px + 2 - 2 * dx;
+                        if (kx < 0 || kx > 4) continue;
+                        for (int ci = 0; ci < Cin; ++ci)
+                            wo[(((int64_t)o * Cin + ci) * 3 + (dy + 1)) * 3 + (dx + 1)] =
+                                wt[(((int64_t)ci * Cout + co) * 5 + ky) * 5 + kx];
+                    }
+                }
+            }
+    return DSVC_OK;
+}

@@ -1,0 +1,367 @@
+// pointwise.hip -- HBM-bound resampling / layout / pointwise kernels of the hot path (NHWC).
+// Each kernel is a grid-stride loop over (pixel, channel-vector) with channels fastest so that a
+// wave touches contiguous bytes (coalesced) -- these ops are judged against the HBM roofline.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned grid_for(int64_t n) {
+    int64_t g = (n + kThreads - 1) / kThreads;
+    const int64_t cap = 256 * 16;  // 16 workgroups per CU, grid-stride beyond
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---- torch_warp (modules.py:25-62) -----------------------------------------------------------
+// grid_sample(bilinear, padding_mode='border', align_corners=True) with grid = base + flow/((size-1)/2):
+// the sampling position in pixels is (x + fx, y + fy), clipped to [0, size-1]; taps beyond the edge
+// carry zero weight.  One thread per (pixel, 4-channel group) when C % 4 == 0, else per element.
+template <int VEC>
+__global__ void warp_kernel(const void* in, int in_ld, int in_dt, const float* flow, int flow_ld,
+                            void* out, int out_ld, int out_dt, int B, int H, int W, int C) {
+    const int cg = (C + VEC - 1) / VEC;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t pix = i / cg;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int64_t b = pix / ((int64_t)W * H);
+        const float fx = flow[pix * flow_ld], fy = flow[pix * flow_ld + 1];
+        float sx = fminf(fmaxf((float)x + fx, 0.f), (float)(W - 1));
+        float sy = fminf(fmaxf((float)y + fy, 0.f), (float)(H - 1));
+        const float x0f = floorf(sx), y0f = floorf(sy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float ax = sx - x0f, ay = sy - y0f;
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
+        const int64_t base = b * H * W;
+        const int64_t o00 = (base + (int64_t)y0 * W + x0) * in_ld, o01 = (base + (int64_t)y0 * W + x1) * in_ld;
+        const int64_t o10 = (base + (int64_t)y1 * W + x0) * in_ld, o11 = (base + (int64_t)y1 * W + x1) * in_ld;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = g * VEC + j;
+            if (c >= C) break;
+            const float v = w00 * load_elem(in, in_dt, o00 + c) + w01 * load_elem(in, in_dt, o01 + c) +
+                            w10 * load_elem(in, in_dt, o10 + c) + w11 * load_elem(in, in_dt, o11 + c);
+            store_elem(out, out_dt, pix * out_ld + c, v);
+        }
+    }
+}
+
+// ---- F.interpolate(x2, bilinear, align_corners=False) * scale (modules.py:107-112,163) ----------
+__global__ void upsample2x_kernel(const float* in, int in_ld, float* out, int out_ld, int B, int H, int W, int C, float scale) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % Wo);
+        const int y = (int)((pix / Wo) % Ho);
+        const int64_t b = pix / ((int64_t)Wo * Ho);
+        const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f), sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int x0 = (int)sx, y0 = (int)sy;
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const float lx = sx - x0, ly = sy - y0;
+        const int64_t base = b * H * W;
+        const float v00 = in[(base + (int64_t)y0 * W + x0) * in_ld + c], v01 = in[(base + (int64_t)y0 * W + x1) * in_ld + c];
+        const float v10 = in[(base + (int64_t)y1 * W + x0) * in_ld + c], v11 = in[(base + (int64_t)y1 * W + x1) * in_ld + c];
+        const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        out[pix * out_ld + c] = v * scale;
+    }
+}
+
+__global__ void pool2x2_kernel(int mode, const void* in, int in_ld, void* out, int out_ld, int dt, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % Wo);
+        const int y = (int)((pix / Wo) % Ho);
+        const int64_t b = pix / ((int64_t)Wo * Ho);
+        const int64_t p00 = ((b * H + 2 * y) * W + 2 * x) * (int64_t)in_ld + c;
+        const float a = load_elem(in, dt, p00), bb = load_elem(in, dt, p00 + in_ld);
+        const float cc = load_elem(in, dt, p00 + (int64_t)W * in_ld), d = load_elem(in, dt, p00 + (int64_t)(W + 1) * in_ld);
+        const float v = mode == 0 ? ((a + bb) + (cc + d)) * 0.25f : fmaxf(fmaxf(a, bb), fmaxf(cc, d));
+        store_elem(out, dt, pix * out_ld + c, v);
+    }
+}
+
+// nn.PixelShuffle(r) reading NCHW fp32, writing NHWC: out[b][y][x][c] = in[b][c*r*r + (y%r)*r + (x%r)][y/r][x/r]
+__global__ void pixel_shuffle_nchw_kernel(const float* in, void* out, int out_ld, int out_dt, int B, int Co, int Hin, int Win, int r) {
+    const int Ho = Hin * r, Wo = Win * r;
+    const int64_t total = (int64_t)B * Ho * Wo * Co;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // iterate x fastest for coalesced reads of the NCHW source; writes are strided by out_ld
+        const int x = (int)(i % Wo);
+        const int c = (int)((i / Wo) % Co);
+        const int y = (int)((i / ((int64_t)Wo * Co)) % Ho);
+        const int64_t b = i / ((int64_t)Wo * Co * Ho);
+        const int cin = c * r * r + (y % r) * r + (x % r);
+        const float v = in[((b * (Co * r * r) + cin) * Hin + y / r) * (int64_t)Win + x / r];
+        store_elem(out, out_dt, ((b * Ho + y) * Wo + x) * (int64_t)out_ld + c, v);
+    }
+}
+
+// layout transposes through an LDS tile so both sides are coalesced
+__global__ void nchw_to_nhwc_kernel(const float* in, void* out, int out_ld, int out_dt, int B, int C, int64_t HW) {
+    __shared__ float tile[32][33];
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int64_t b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k;
+        const int64_t pp = p0 + tx;
+        tile[k][tx] = (c < C && pp < HW) ? in[(b * C + c) * HW + pp] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t pp = p0 + k;
+        const int c = c0 + tx;
+        if (c < C && pp < HW) store_elem(out, out_dt, (b * HW + pp) * out_ld + c, tile[tx][k]);
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const void* in, int in_ld, int in_dt, float* out, int B, int C, int64_t HW) {
+    __shared__ float tile[32][33];
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int64_t b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t pp = p0 + k;
+        const int c = c0 + tx;
+        tile[k][tx] = (c < C && pp < HW) ? load_elem(in, in_dt, (b * HW + pp) * in_ld + c) : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k;
+        const int64_t pp = p0 + tx;
+        if (c < C && pp < HW) out[(b * C + c) * HW + pp] = tile[tx][k];
+    }
+}
+
+struct Opnd { const void* p; int ld, dt; };
+
+__global__ void eltwise_kernel(int op, int64_t n_pix, int C, Opnd a, Opnd b, Opnd c, Opnd d, Opnd e,
+                               void* out, int out_ld, int out_dt) {
+    const int64_t total = n_pix * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % C);
+        const int64_t pix = i / C;
+        const float va = load_elem(a.p, a.dt, pix * a.ld + ch);
+        float v;
+        switch (op) {
+            case DSVC_EW_ADD: v = va + load_elem(b.p, b.dt, pix * b.ld + ch); break;
+            case DSVC_EW_SUB: v = va - load_elem(b.p, b.dt, pix * b.ld + ch); break;
+            case DSVC_EW_BLEND2: {
+                const float w = load_elem(d.p, d.dt, pix * d.ld + ch);
+                v = w * va + (1.f - w) * load_elem(b.p, b.dt, pix * b.ld + ch);
+                break;
+            }
+            case DSVC_EW_BLEND3: {
+                const float w = load_elem(d.p, d.dt, pix * d.ld + ch), u = load_elem(e.p, e.dt, pix * e.ld + ch);
+                v = w * va + u * load_elem(b.p, b.dt, pix * b.ld + ch) + (1.f - w - u) * load_elem(c.p, c.dt, pix * c.ld + ch);
+                break;
+            }
+            case DSVC_EW_CLAMP01: v = fminf(fmaxf(va, 0.f), 1.f); break;
+            default: v = va; break;
+        }
+        store_elem(out, out_dt, pix * out_ld + ch, v);
+    }
+}
+
+// ---- SELayer (modules.py:217-230), deterministic two-stage mean ----------------------------------
+constexpr int kSeBlocks = 512;   // partial sums per image
+__global__ void se_partial_kernel(const void* x, int ld, int dt, int64_t HW, int C, float* partial) {
+    // block (j, b): pixels j, j+kSeBlocks, ...; thread t handles channel t % C, pixel lane t / C
+    extern __shared__ float red[];
+    const int b = blockIdx.y, j = blockIdx.x;
+    const int lanes = blockDim.x / C;  // pixel lanes per block (C <= 256 and divides 256 on this path)
+    const int c = threadIdx.x % C, pl = threadIdx.x / C;
+    float s = 0.f;
+    if (pl < lanes)
+        for (int64_t p = (int64_t)j * lanes + pl; p < HW; p += (int64_t)kSeBlocks * lanes)
+            s += load_elem(x, dt, ((int64_t)b * HW + p) * ld + c);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int k = 0; k < lanes; ++k) t += red[k * C + threadIdx.x];
+        partial[((int64_t)b * kSeBlocks + j) * C + threadIdx.x] = t;
+    }
+}
+
+__global__ void se_gate_kernel(const float* partial, int64_t HW, int C, int hidden, const float* w1, const float* w2, float* gate) {
+    extern __shared__ float sm[];  // mean[C] + hid[hidden]
+    float* mean = sm;
+    float* hid = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0;
+        for (int j = 0; j < kSeBlocks; ++j) s += (double)partial[((int64_t)b * kSeBlocks + j) * C + c];
+        mean[c] = (float)(s / (double)HW);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < hidden; k += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += w1[k * C + c] * mean[c];
+        hid[k] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < hidden; ++k) s += w2[c * hidden + k] * hid[k];
+        gate[(int64_t)b * C + c] = 1.f / (1.f + expf(-s));
+    }
+}
+
+// ---- deterministic reductions -------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;
+__global__ void reduce_partial_kernel(int mode, int64_t n_pix, int C, Opnd a, Opnd b, float* partial) {
+    __shared__ double red[kThreads];
+    const int64_t total = n_pix * C;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % C);
+        const int64_t pix = i / C;
+        const float va = load_elem(a.p, a.dt, pix * a.ld + ch);
+        if (mode == 0) s += va;
+        else if (mode == 1) s += logf(va);
+        else { const float dd = va - load_elem(b.p, b.dt, pix * b.ld + ch); s += dd * dd; }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = kThreads / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ((double*)partial)[blockIdx.x] = red[0];
+}
+__global__ void reduce_final_kernel(const float* partial, int n, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += ((const double*)partial)[i];
+        out[0] = s;
+    }
+}
+
+inline Opnd mk(const dsvc_operand* o) { return o ? Opnd{o->ptr, o->ld, o->dtype} : Opnd{nullptr, 0, 0}; }
+inline bool dt_ok(int dt) { return dt == DSVC_F32 || dt == DSVC_BF16; }
+
+}  // namespace
+
+extern "C" int dsvc_warp_bilinear_border(void* stream, const void* in, int32_t in_ld, int32_t in_dtype,
+                                         const float* flow, int32_t flow_ld, void* out, int32_t out_ld, int32_t out_dtype,
+                                         int32_t B, int32_t H, int32_t W, int32_t C) {
+    DSVC_REQUIRE(in && flow && out, "warp: null pointer");
+    DSVC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && in_ld >= C && out_ld >= C && flow_ld >= 2, "warp: bad shape");
+    DSVC_REQUIRE(dt_ok(in_dtype) && dt_ok(out_dtype), "warp: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0) {
+        const int64_t n = (int64_t)B * H * W * (C / 4);
+        hipLaunchKernelGGL(warp_kernel<4>, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+    } else {
+        const int64_t n = (int64_t)B * H * W * C;
+        hipLaunchKernelGGL(warp_kernel<1>, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+    }
+    DSVC_CHECK_LAUNCH("warp_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int dsvc_upsample2x_bilinear(void* stream, const float* in, int32_t in_ld, float* out, int32_t out_ld,
+                                        int32_t B, int32_t H, int32_t W, int32_t C, float scale) {
+    DSVC_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0 && in_ld >= C && out_ld >= C, "upsample2x: bad argument");
+    const int64_t n = (int64_t)B * 4 * H * W * C;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, in, in_ld, out, out_ld, B, H, W, C, scale);
+    DSVC_CHECK_LAUNCH("upsample2x_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int dsvc_pool2x2(void* stream, int32_t mode, const void* in, int32_t in_ld, void* out, int32_t out_ld,
+                            int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C) {
+    DSVC_REQUIRE(in && out && (mode == 0 || mode == 1) && dt_ok(dtype), "pool2x2: bad argument");
+    DSVC_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0 && in_ld >= C && out_ld >= C, "pool2x2: bad shape H=%d W=%d", H, W);
+    const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
+    hipLaunchKernelGGL(pool2x2_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, dtype, B, H, W, C);
+    DSVC_CHECK_LAUNCH("pool2x2_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int dsvc_pixel_shuffle_nchw(void* stream, const float* in, void* out, int32_t out_ld, int32_t out_dtype,
+                                       int32_t B, int32_t Cout, int32_t Hin, int32_t Win, int32_t r) {
+    DSVC_REQUIRE(in && out && B > 0 && Cout > 0 && Hin > 0 && Win > 0 && r >= 1 && out_ld >= Cout && dt_ok(out_dtype), "pixel_shuffle: bad argument");
+    const int64_t n = (int64_t)B * Cout * Hin * r * Win * r;
+    hipLaunchKernelGGL(pixel_shuffle_nchw_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, out_dtype, B, Cout, Hin, Win, r);
+    DSVC_CHECK_LAUNCH("pixel_shuffle_nchw_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int dsvc_nchw_to_nhwc(void* stream, const float* in, void* out, int32_t out_ld, int32_t out_dtype,
+                                 int32_t B, int32_t C, int32_t H, int32_t W) {
+    DSVC_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0 && out_ld >= C && dt_ok(out_dtype), "nchw_to_nhwc: bad argument");
+    const int64_t HW = (int64_t)H * W;
+    dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, out_ld, out_dtype, B, C, HW);
+    DSVC_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int dsvc_nhwc_to_nchw(void* stream, const void* in, int32_t in_ld, int32_t in_dtype, float* out,
+                                 int32_t B, int32_t C, int32_t H, int32_t W) {
+    DSVC_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0 && in_ld >= C && dt_ok(in_dtype), "nhwc_to_nchw: bad argument");
+    const int64_t HW = (int64_t)H * W;
+    dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, in_ld, in_dtype, out, B, C, HW);
+    DSVC_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int dsvc_eltwise(void* stream, int32_t op, int64_t n_pix, int32_t C, const dsvc_operand* a,
+                            const dsvc_operand* b, const dsvc_operand* c, const dsvc_operand* d, const dsvc_operand* e,
+                            void* out, int32_t out_ld, int32_t out_dtype) {
+    DSVC_REQUIRE(a && a->ptr && out && n_pix > 0 && C > 0 && out_ld >= C && dt_ok(out_dtype), "eltwise: bad argument");
+    DSVC_REQUIRE(op >= DSVC_EW_COPY && op <= DSVC_EW_CLAMP01, "eltwise: unknown op %d", op);
+    const bool need_b = op == DSVC_EW_ADD || op == DSVC_EW_SUB || op == DSVC_EW_BLEND2 || op == DSVC_EW_BLEND3;
+    DSVC_REQUIRE(!need_b || (b && b->ptr), "eltwise: operand b missing");
+    DSVC_REQUIRE(!(op == DSVC_EW_BLEND2 || op == DSVC_EW_BLEND3) || (d && d->ptr), "eltwise: operand d missing");
+    DSVC_REQUIRE(op != DSVC_EW_BLEND3 || (c && c->ptr && e && e->ptr), "eltwise: operands c/e missing");
+    hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n_pix * C)), dim3(kThreads), 0, (hipStream_t)stream, op, n_pix, C,
+                       mk(a), mk(b), mk(c), mk(d), mk(e), out, out_ld, out_dtype);
+    DSVC_CHECK_LAUNCH("eltwise_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int64_t dsvc_se_workspace_floats(int32_t B, int32_t C) { return (int64_t)B * kSeBlocks * C; }
+
+extern "C" int dsvc_se_gate(void* stream, const void* x, int32_t ld, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                            const float* w1, const float* w2, int32_t hidden, float* partial, float* gate) {
+    DSVC_REQUIRE(x && w1 && w2 && partial && gate && dt_ok(dtype), "se_gate: null/bad argument");
+    DSVC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C <= 256 && 256 % C == 0 && hidden > 0 && ld >= C, "se_gate: C=%d must divide 256", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t HW = (int64_t)H * W;
+    hipLaunchKernelGGL(se_partial_kernel, dim3(kSeBlocks, B), dim3(256), 256 * sizeof(float), st, x, ld, dtype, HW, C, partial);
+    DSVC_CHECK_LAUNCH("se_partial_kernel");
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (C + hidden) * sizeof(float), st, partial, HW, C, hidden, w1, w2, gate);
+    DSVC_CHECK_LAUNCH("se_gate_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int64_t dsvc_reduce_workspace_floats(void) { return 2 * kRedBlocks; }
+
+extern "C" int dsvc_reduce(void* stream, int32_t mode, int64_t n_pix, int32_t C, const dsvc_operand* a, const dsvc_operand* b,
+                           float* partial, double* out) {
+    DSVC_REQUIRE(a && a->ptr && partial && out && n_pix > 0 && C > 0 && mode >= 0 && mode <= 2, "reduce: bad argument");
+    DSVC_REQUIRE(mode != 2 || (b && b->ptr), "reduce: operand b missing");
+    DSVC_REQUIRE(((uintptr_t)partial & 7) == 0, "reduce: workspace must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t g = (n_pix * C + kThreads - 1) / kThreads;
+    const int nb = (int)(g < kRedBlocks ? g : kRedBlocks);
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(kThreads), 0, st, mode, n_pix, C, mk(a), mk(b), partial);
+    DSVC_CHECK_LAUNCH("reduce_partial_kernel");
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, nb, out);
+    DSVC_CHECK_LAUNCH("reduce_final_kernel");
+    return DSVC_OK;
+}

@@ -1,0 +1,189 @@
+// rans_host.cpp -- host range coder of the hot path (product code).
+//
+// Replaces compressai.ans.BufferedRansEncoder / RansDecoder as called from
+// image_model.py:221,253-254,273-274,288 (and inside EntropyBottleneck.compress/decompress,
+// image_model.py:206-207,260).  Bitstream format = compressai 1.2.1 rans_interface.cpp over
+// ryg_rans rans64.h: 64-bit state, L = 2^31, 32-bit renormalisation words,
+// 16-bit probabilities, out-of-range symbols escaped through 4-bit bypass nibbles; symbols are
+// pushed in order and coded in reverse; the stream is the little-endian word sequence.
+//
+// Implementation notes (differs from the straightforward form on purpose):
+//   * the pending list stores one packed 32-bit entry per coded item (start:16 | (range-1):16,
+//     bypass items tagged by an out-of-band bitmap) -- half the memory traffic of a struct list;
+//   * the decoder's symbol search is a branch-light binary search over the CDF row instead of a
+//     linear scan (rows reach 3133 entries for sigma = 256); results are identical by construction.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "common.h"
+
+namespace {
+constexpr uint32_t kPrecision = 16;
+constexpr uint32_t kBypassBits = 4;
+constexpr int32_t kBypassMax = 15;
+constexpr uint64_t kRansL = 1ull << 31;
+
+struct Encoder {
+    std::vector<uint32_t> items;   // start | (range-1) << 16
+    std::vector<uint8_t> bypass;   // 1 when the item is a bypass nibble
+    std::vector<uint32_t> words;   // scratch for flush()
+    int64_t nbytes = -1;           // valid after a size query
+    int64_t first = 0;
+};
+
+struct Decoder {
+    std::vector<uint32_t> words;
+    size_t pos = 2;
+    uint64_t x = 0;
+    inline void renorm() {
+        if (x < kRansL) {
+            const uint32_t w = pos < words.size() ? words[pos] : 0u;
+            ++pos;
+            x = (x << 32) | w;
+        }
+    }
+    inline uint32_t bits() {
+        const uint32_t v = (uint32_t)(x & kBypassMax);
+        x >>= kBypassBits;
+        renorm();
+        return v;
+    }
+};
+
+inline void push(Encoder* e, uint32_t start, uint32_t range, bool bp) {
+    e->items.push_back((start & 0xFFFFu) | ((range - 1) << 16));
+    e->bypass.push_back(bp ? 1 : 0);
+}
+
+bool table_ok(const dsvc_cdf_table* t) {
+    return t && t->cdf && t->cdf_length && t->offset && t->rows > 0 && t->stride > 1;
+}
+}  // namespace
+
+extern "C" int dsvc_rans_encoder_create(void** enc) {
+    DSVC_REQUIRE(enc != nullptr, "rans_encoder_create: null out pointer");
+    *enc = new Encoder();
+    return DSVC_OK;
+}
+
+extern "C" void dsvc_rans_encoder_destroy(void* enc) { delete (Encoder*)enc; }
+
+extern "C" int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, const int32_t* indexes, int64_t n,
+                                             const dsvc_cdf_table* t) {
+    DSVC_REQUIRE(enc && symbols && indexes && n >= 0, "rans_encode: null argument");
+    DSVC_REQUIRE(table_ok(t), "rans_encode: bad cdf table");
+    Encoder* e = (Encoder*)enc;
+    e->nbytes = -1;
+    e->items.reserve(e->items.size() + (size_t)n + 64);
+    e->bypass.reserve(e->bypass.size() + (size_t)n + 64);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t ci = indexes[i];
+        DSVC_REQUIRE(ci >= 0 && ci < t->rows, "rans_encode: cdf index %d out of range at %lld", ci, (long long)i);
+        const int32_t* row = t->cdf + (int64_t)ci * t->stride;
+        const int32_t max_value = t->cdf_length[ci] - 2;
+        DSVC_REQUIRE(max_value >= 0 && max_value + 1 < t->stride, "rans_encode: cdf_length[%d] invalid", ci);
+        int32_t v = symbols[i] - t->offset[ci];
+        uint32_t raw = 0;
+        if (v < 0) { raw = (uint32_t)(-2 * (int64_t)v - 1); v = max_value; }
+        else if (v >= max_value) { raw = (uint32_t)(2 * (int64_t)(v - max_value)); v = max_value; }
+        push(e, (uint32_t)row[v], (uint32_t)(row[v + 1] - row[v]), false);
+        if (v == max_value) {
+            int32_t nb = 0;
+            while (nb < 8 && (raw >> (nb * kBypassBits)) != 0) ++nb;
+            int32_t val = nb;
+            while (val >= kBypassMax) { push(e, kBypassMax, kBypassMax + 1, true); val -= kBypassMax; }
+            push(e, (uint32_t)val, (uint32_t)val + 1, true);
+            for (int32_t j = 0; j < nb; ++j) {
+                const uint32_t nib = (raw >> (j * kBypassBits)) & kBypassMax;
+                push(e, nib, nib + 1, true);
+            }
+        }
+    }
+    return DSVC_OK;
+}
+
+extern "C" int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap) {
+    if (!enc) { dsvc_set_error("rans_flush: null encoder"); return DSVC_E_ARG; }
+    Encoder* e = (Encoder*)enc;
+    if (e->nbytes < 0) {
+        const size_t m = e->items.size();
+        e->words.assign(m + 4, 0u);  // every item emits at most one word; +2 state words
+        size_t p = e->words.size();
+        uint64_t x = kRansL;
+        for (size_t k = m; k-- > 0;) {
+            const uint32_t it = e->items[k];
+            const uint32_t start = it & 0xFFFFu;
+            if (!e->bypass[k]) {
+                const uint64_t freq = (uint64_t)(it >> 16) + 1;
+                const uint64_t x_max = ((kRansL >> kPrecision) << 32) * freq;
+                if (x >= x_max) { e->words[--p] = (uint32_t)x; x >>= 32; }
+                x = ((x / freq) << kPrecision) + (x % freq) + start;
+            } else {
+                const uint64_t x_max = ((kRansL >> 16) << 32) * (1ull << (16 - kBypassBits));
+                if (x >= x_max) { e->words[--p] = (uint32_t)x; x >>= 32; }
+                x = (x << kBypassBits) | start;
+            }
+        }
+        p -= 2;
+        e->words[p] = (uint32_t)x;
+        e->words[p + 1] = (uint32_t)(x >> 32);
+        e->first = (int64_t)p;
+        e->nbytes = (int64_t)(e->words.size() - p) * 4;
+    }
+    if (!out) return e->nbytes;
+    if (cap < e->nbytes) { dsvc_set_error("rans_flush: buffer %lld < %lld", (long long)cap, (long long)e->nbytes); return DSVC_E_RANGE; }
+    std::memcpy(out, e->words.data() + e->first, (size_t)e->nbytes);  // x86-64: little endian == stream order
+    const int64_t nb = e->nbytes;
+    e->items.clear(); e->bypass.clear(); e->nbytes = -1;
+    return nb;
+}
+
+extern "C" int dsvc_rans_decoder_create(void** dec, const uint8_t* data, int64_t nbytes) {
+    DSVC_REQUIRE(dec && data && nbytes >= 8 && nbytes % 4 == 0, "rans_decoder_create: need >= 8 bytes, multiple of 4 (got %lld)", (long long)nbytes);
+    Decoder* d = new Decoder();
+    d->words.resize((size_t)nbytes / 4);
+    std::memcpy(d->words.data(), data, (size_t)nbytes);
+    d->x = (uint64_t)d->words[0] | ((uint64_t)d->words[1] << 32);
+    d->pos = 2;
+    *dec = d;
+    return DSVC_OK;
+}
+
+extern "C" void dsvc_rans_decoder_destroy(void* dec) { delete (Decoder*)dec; }
+
+extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_t n, const dsvc_cdf_table* t, int32_t* out) {
+    DSVC_REQUIRE(dec && indexes && out && n >= 0, "rans_decode: null argument");
+    DSVC_REQUIRE(table_ok(t), "rans_decode: bad cdf table");
+    Decoder* d = (Decoder*)dec;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t ci = indexes[i];
+        DSVC_REQUIRE(ci >= 0 && ci < t->rows, "rans_decode: cdf index %d out of range at %lld", ci, (long long)i);
+        const int32_t* row = t->cdf + (int64_t)ci * t->stride;
+        const int32_t len = t->cdf_length[ci];
+        const int32_t max_value = len - 2;
+        const uint32_t cf = (uint32_t)(d->x & 0xFFFFu);
+        // largest s in [0, len-2] with row[s] <= cf  (row[0] = 0, row[len-1] = 65536 > cf)
+        int32_t lo = 0, hi = len - 1;
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
+        }
+        const int32_t s = lo;
+        const uint32_t start = (uint32_t)row[s], freq = (uint32_t)(row[s + 1] - row[s]);
+        d->x = (uint64_t)freq * (d->x >> kPrecision) + cf - start;
+        d->renorm();
+        int32_t v = s;
+        if (v == max_value) {
+            int32_t val = (int32_t)d->bits(), nb = val;
+            while (val == kBypassMax) { val = (int32_t)d->bits(); nb += val; }
+            uint32_t raw = 0;
+            for (int32_t j = 0; j < nb && j < 8; ++j) raw |= d->bits() << (j * kBypassBits);
+            v = (int32_t)(raw >> 1);
+            v = (raw & 1u) ? -v - 1 : v + max_value;
+        }
+        out[i] = v + t->offset[ci];
+        if (d->pos > d->words.size() + 2) { dsvc_set_error("rans_decode: stream exhausted at symbol %lld", (long long)i); return DSVC_E_RANGE; }
+    }
+    return DSVC_OK;
+}

@@ -1,0 +1,375 @@
+"""Host-side op layer: NHWC activation slices (`Act`) + thin wrappers over the C ABI (libdsvc.so).
+
+PyTorch is used here for device memory (torch.empty), streams and dtype tags only; every compute
+step is a hand-written HIP kernel reached through `deepsvc_amd._native`.  CPU tensors are refused:
+the product has no CPU path (the CPU restatement lives in `oracle/` and is test infrastructure).
+"""
+import ctypes
+from ctypes import byref
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+_TORCH2CODE = {torch.float32: N.F32, torch.bfloat16: N.BF16}
+
+
+class Precision:
+    """compute: MFMA input type of the conv kernels; storage: default activation storage type."""
+
+    def __init__(self):
+        self.compute = N.F32
+        self.storage = torch.float32
+
+    def set(self, mode):
+        if mode == "fp32":
+            self.compute, self.storage = N.F32, torch.float32
+        elif mode == "bf16":
+            self.compute, self.storage = N.BF16, torch.bfloat16
+        else:
+            raise ValueError(f"unknown precision mode {mode!r} (use 'fp32' or 'bf16')")
+        self.mode = mode
+
+    mode = "fp32"
+
+
+RT = Precision()
+
+
+def set_precision(mode):
+    RT.set(mode)
+
+
+def get_precision():
+    return RT.mode
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise N.NativeError("deepsvc_amd ops run on the GPU only (got a CPU tensor); "
+                            "the CPU restatement is oracle/ and is not a product path")
+
+
+class Act:
+    """An NHWC activation: channels [c0, c0+C) of a contiguous torch buffer [B, H, W, ld]."""
+    __slots__ = ("buf", "c0", "C")
+
+    def __init__(self, buf, c0=0, C=None):
+        assert buf.dim() == 4 and buf.is_contiguous()
+        self.buf, self.c0 = buf, c0
+        self.C = buf.shape[3] - c0 if C is None else C
+
+    B = property(lambda s: s.buf.shape[0])
+    H = property(lambda s: s.buf.shape[1])
+    W = property(lambda s: s.buf.shape[2])
+    ld = property(lambda s: s.buf.shape[3])
+    dtype = property(lambda s: s.buf.dtype)
+    code = property(lambda s: _TORCH2CODE[s.buf.dtype])
+    device = property(lambda s: s.buf.device)
+    npix = property(lambda s: s.buf.shape[0] * s.buf.shape[1] * s.buf.shape[2])
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.c0 * self.buf.element_size()
+
+    def ch(self, c0, C):
+        assert 0 <= c0 and c0 + C <= self.C
+        return Act(self.buf, self.c0 + c0, C)
+
+    def operand(self):
+        return N.Operand(self.ptr, self.ld, self.code)
+
+    def nchw_view(self):
+        """Zero-copy logical-NCHW view in the storage dtype (channels_last strides)."""
+        return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
+
+    def nchw(self):
+        """Logical NCHW fp32 view/copy for the reference-style API."""
+        if self.dtype == torch.float32:
+            return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
+        out = torch.empty((self.B, self.C, self.H, self.W), dtype=torch.float32, device=self.device)
+        N.check(N.lib().dsvc_nhwc_to_nchw(_stream(), self.ptr, self.ld, self.code, out.data_ptr(),
+                                          self.B, self.C, self.H, self.W), "nhwc_to_nchw")
+        return out
+
+
+def new_act(B, H, W, C, dtype=None, device=None, ld=None):
+    ld = C if ld is None else ld
+    return Act(torch.empty((B, H, W, ld), dtype=dtype or RT.storage, device=device), 0, C)
+
+
+def to_act(x, dtype=None):
+    """Reference-style tensor [B,C,H,W] -> Act.  Zero-copy when x is fp32 channels_last memory."""
+    if isinstance(x, Act):
+        return x
+    _require_gpu(x)
+    assert x.dim() == 4, "expected an NCHW tensor"
+    want = dtype or torch.float32
+    xp = x.permute(0, 2, 3, 1)
+    if x.dtype == want and xp.is_contiguous():
+        return Act(xp)
+    B, C, H, W = x.shape
+    src = x.to(torch.float32).contiguous() if (x.dtype != torch.float32 or not x.is_contiguous()) else x
+    out = new_act(B, H, W, C, want, x.device)
+    N.check(N.lib().dsvc_nchw_to_nhwc(_stream(), src.data_ptr(), out.ptr, out.ld, out.code, B, C, H, W), "nchw_to_nhwc")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------------
+class PackedConv:
+    """Device-resident packed weights (+ fp32 bias) of one conv for one (segments, compute type)."""
+
+    def __init__(self, w_oihw, bias, seg_channels, stride, pad, compute, device):
+        w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+        self.Cout, cin, self.kh, self.kw = w.shape
+        assert sum(seg_channels) == cin, f"segments {seg_channels} do not add up to Cin={cin}"
+        self.segC = tuple(int(c) for c in seg_channels)
+        self.stride, self.pad, self.compute = stride, pad, compute
+        segs = (ctypes.c_int32 * len(self.segC))(*self.segC)
+        L = N.lib()
+        nbytes = L.dsvc_conv_packed_bytes(self.Cout, len(self.segC), segs, self.kh, self.kw, compute)
+        N.check(nbytes, "conv_packed_bytes")
+        host = np.empty(nbytes, dtype=np.uint8)
+        N.check(L.dsvc_conv_pack_weights(w.data_ptr(), self.Cout, len(self.segC), segs, self.kh, self.kw, compute,
+                                         host.ctypes.data), "conv_pack_weights")
+        self.weight = torch.from_numpy(host).to(device)
+        self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+
+
+def deconv_as_conv_weights(w_iohw, bias):
+    """ConvTranspose2d(5,s2,p2,op1) parameters -> (3x3 conv weight [4*Cout,Cin,3,3], bias [4*Cout]) on the host."""
+    w = w_iohw.detach().to("cpu", torch.float32).contiguous()
+    cin, cout = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (5, 5)
+    wo = torch.empty((4 * cout, cin, 3, 3), dtype=torch.float32)
+    bo = torch.empty(4 * cout, dtype=torch.float32)
+    b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+    N.check(N.lib().dsvc_deconv5x5s2_to_conv3x3(w.data_ptr(), None if b is None else b.data_ptr(), cin, cout,
+                                                wo.data_ptr(), bo.data_ptr()), "deconv_to_conv")
+    return wo, bo
+
+
+def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.01, res1=None, gate=None, res2=None,
+           shuffle=1, out_dtype=None):
+    """Run one fused conv.  inputs: list of Act (virtual torch.cat along channels)."""
+    x0 = inputs[0]
+    _require_gpu(x0.buf)
+    assert tuple(a.C for a in inputs) == pc.segC, f"input channels {[a.C for a in inputs]} != packed segments {pc.segC}"
+    B, H, W = x0.B, x0.H, x0.W
+    Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.kw) // pc.stride + 1
+    if out is None:
+        out = new_act(B, Ho * shuffle, Wo * shuffle, pc.Cout // (shuffle * shuffle), out_dtype, x0.device)
+    else:
+        assert (out.B, out.H, out.W, out.C) == (B, Ho * shuffle, Wo * shuffle, pc.Cout // (shuffle * shuffle)), \
+            f"out shape {(out.B, out.H, out.W, out.C)} mismatch"
+    d = N.ConvDesc()
+    d.B, d.H, d.W, d.nseg = B, H, W, len(inputs)
+    for i, a in enumerate(inputs):
+        assert (a.B, a.H, a.W) == (B, H, W)
+        d.seg[i].ptr, d.seg[i].C, d.seg[i].ld, d.seg[i].dtype = a.ptr, a.C, a.ld, a.code
+    d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, pc.stride, pc.pad
+    d.Cout, d.compute = pc.Cout, pc.compute
+    d.weight = pc.weight.data_ptr()
+    d.bias = None if pc.bias is None else pc.bias.data_ptr()
+    d.pre_act, d.act, d.slope = pre_act, act, slope
+    if res1 is not None:
+        assert (res1.B, res1.H, res1.W, res1.C) == (out.B, out.H, out.W, out.C)
+        d.res1, d.res1_ld, d.res1_dtype = res1.ptr, res1.ld, res1.code
+    if gate is not None:
+        assert gate.dtype == torch.float32 and gate.numel() == B * pc.Cout
+        d.res1_scale = gate.data_ptr()
+    if res2 is not None:
+        assert (res2.B, res2.H, res2.W, res2.C) == (out.B, out.H, out.W, out.C)
+        d.res2, d.res2_ld, d.res2_dtype = res2.ptr, res2.ld, res2.code
+    d.shuffle = shuffle
+    d.out, d.out_ld, d.out_dtype = out.ptr, out.ld, out.code
+    N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# resampling / layout / pointwise
+# --------------------------------------------------------------------------------------------
+def warp(x, flow, out=None):
+    assert flow.dtype == torch.float32 and flow.C == 2
+    out = out or new_act(x.B, x.H, x.W, x.C, x.dtype, x.device)
+    N.check(N.lib().dsvc_warp_bilinear_border(_stream(), x.ptr, x.ld, x.code, flow.ptr, flow.ld, out.ptr, out.ld, out.code,
+                                              x.B, x.H, x.W, x.C), "warp")
+    return out
+
+
+def upsample2x(x, scale=1.0, out=None):
+    assert x.dtype == torch.float32
+    out = out or new_act(x.B, 2 * x.H, 2 * x.W, x.C, torch.float32, x.device)
+    N.check(N.lib().dsvc_upsample2x_bilinear(_stream(), x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, x.C, float(scale)), "upsample2x")
+    return out
+
+
+def pool2x2(x, mode, out=None):
+    out = out or new_act(x.B, x.H // 2, x.W // 2, x.C, x.dtype, x.device)
+    assert out.dtype == x.dtype
+    N.check(N.lib().dsvc_pool2x2(_stream(), 0 if mode == "avg" else 1, x.ptr, x.ld, out.ptr, out.ld, x.code, x.B, x.H, x.W, x.C), "pool2x2")
+    return out
+
+
+def pixel_shuffle_nchw(x_nchw, r, out=None, dtype=None):
+    _require_gpu(x_nchw)
+    x = x_nchw.to(torch.float32).contiguous()
+    B, C, H, W = x.shape
+    co = C // (r * r)
+    out = out or new_act(B, H * r, W * r, co, dtype, x.device)
+    N.check(N.lib().dsvc_pixel_shuffle_nchw(_stream(), x.data_ptr(), out.ptr, out.ld, out.code, B, co, H, W, r), "pixel_shuffle")
+    return out
+
+
+def _op(a):
+    return None if a is None else byref(a.operand())
+
+
+def eltwise(op, a, b=None, c=None, d=None, e=None, out=None, out_dtype=None):
+    out = out or new_act(a.B, a.H, a.W, a.C, out_dtype or a.dtype, a.device)
+    N.check(N.lib().dsvc_eltwise(_stream(), op, a.npix, a.C, _op(a), _op(b), _op(c), _op(d), _op(e), out.ptr, out.ld, out.code), "eltwise")
+    return out
+
+
+def se_gate(x, w1, w2):
+    """SELayer gate [B, C] fp32 for activation x (w1 [C/r, C], w2 [C, C/r] device fp32)."""
+    L = N.lib()
+    ws = torch.empty(L.dsvc_se_workspace_floats(x.B, x.C), dtype=torch.float32, device=x.device)
+    gate = torch.empty((x.B, x.C), dtype=torch.float32, device=x.device)
+    N.check(L.dsvc_se_gate(_stream(), x.ptr, x.ld, x.code, x.B, x.H, x.W, x.C, w1.data_ptr(), w2.data_ptr(), w1.shape[0],
+                           ws.data_ptr(), gate.data_ptr()), "se_gate")
+    return gate
+
+
+def reduce(mode, a, b=None):
+    """mode: 'sum' | 'sumlog' | 'sqdiff' -> 0-dim fp64 device tensor."""
+    L = N.lib()
+    ws = torch.empty(L.dsvc_reduce_workspace_floats(), dtype=torch.float32, device=a.device)
+    out = torch.empty((), dtype=torch.float64, device=a.device)
+    N.check(L.dsvc_reduce(_stream(), {"sum": 0, "sumlog": 1, "sqdiff": 2}[mode], a.npix, a.C, _op(a), _op(b),
+                          ws.data_ptr(), out.data_ptr()), "reduce")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# entropy-model device arithmetic
+# --------------------------------------------------------------------------------------------
+def gc_quantize(y, mu, scale, table, want_symbols=True, want_indexes=True, y_hat=None, sym_out=None, idx_out=None):
+    """sym_out / idx_out: optional preallocated int32 device vectors (views into a staging buffer)."""
+    B, H, W, C = mu.B, mu.H, mu.W, mu.C
+    dev, n = mu.device, mu.B * mu.C * mu.H * mu.W
+    sym = (sym_out if sym_out is not None else torch.empty(n, dtype=torch.int32, device=dev)) if want_symbols else None
+    idx = (idx_out if idx_out is not None else torch.empty(n, dtype=torch.int32, device=dev)) if want_indexes else None
+    assert (sym is None or (sym.numel() == n and sym.dtype == torch.int32)) and (idx is None or (idx.numel() == n and idx.dtype == torch.int32))
+    N.check(N.lib().dsvc_gc_quantize(_stream(), None if y is None else y.ptr, 0 if y is None else y.ld, mu.ptr, mu.ld,
+                                     None if scale is None else scale.ptr, 0 if scale is None else scale.ld, mu.code,
+                                     table.data_ptr(), table.numel(), B, H, W, C,
+                                     None if sym is None else sym.data_ptr(), None if idx is None else idx.data_ptr(),
+                                     None if y_hat is None else y_hat.ptr, 0 if y_hat is None else y_hat.ld), "gc_quantize")
+    return sym, idx
+
+
+def gc_dequantize(symbols, mu, y_hat):
+    N.check(N.lib().dsvc_gc_dequantize(_stream(), symbols.data_ptr(), mu.ptr, mu.ld, mu.code, mu.B, mu.H, mu.W, mu.C,
+                                       y_hat.ptr, y_hat.ld), "gc_dequantize")
+    return y_hat
+
+
+def gc_likelihood(y, mu, scale, y_hat=None, lik=None):
+    N.check(N.lib().dsvc_gc_likelihood(_stream(), y.ptr, y.ld, mu.ptr, mu.ld, scale.ptr, scale.ld, mu.code, mu.npix, mu.C,
+                                       None if y_hat is None else y_hat.ptr, 0 if y_hat is None else y_hat.ld,
+                                       None if lik is None else lik.ptr, 0 if lik is None else lik.ld), "gc_likelihood")
+
+
+def eb_process(z, params, symbols=False, z_hat=None, lik=None, sym_out=None):
+    B, H, W, C = z.B, z.H, z.W, z.C
+    sym = (sym_out if sym_out is not None else torch.empty(B * C * H * W, dtype=torch.int32, device=z.device)) if symbols else None
+    mode = (1 if symbols else 0) | (2 if z_hat is not None else 0) | (4 if lik is not None else 0)
+    N.check(N.lib().dsvc_eb_process(_stream(), z.ptr, z.ld, z.code, params.data_ptr(), B, H, W, C, mode,
+                                    None if sym is None else sym.data_ptr(),
+                                    None if z_hat is None else z_hat.ptr, 0 if z_hat is None else z_hat.ld,
+                                    None if lik is None else lik.ptr, 0 if lik is None else lik.ld), "eb_process")
+    return sym
+
+
+def eb_dequantize(symbols, params, z_hat):
+    N.check(N.lib().dsvc_eb_dequantize(_stream(), symbols.data_ptr(), params.data_ptr(), z_hat.code, z_hat.B, z_hat.H, z_hat.W,
+                                       z_hat.C, z_hat.ptr, z_hat.ld), "eb_dequantize")
+    return z_hat
+
+
+# --------------------------------------------------------------------------------------------
+# host coder
+# --------------------------------------------------------------------------------------------
+class CdfTables:
+    """Integer CDF tables (host, int32) in the layout the C coder takes."""
+
+    def __init__(self, cdf, cdf_length, offset):
+        self.cdf = np.ascontiguousarray(cdf, dtype=np.int32)
+        self.cdf_length = np.ascontiguousarray(cdf_length, dtype=np.int32).reshape(-1)
+        self.offset = np.ascontiguousarray(offset, dtype=np.int32).reshape(-1)
+        self.c = N.CdfTable(self.cdf.ctypes.data, self.cdf.shape[0], self.cdf.shape[1],
+                            self.cdf_length.ctypes.data, self.offset.ctypes.data)
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    p = np.ascontiguousarray(pmf, dtype=np.float32)
+    out = np.empty(len(p) + 1, dtype=np.int32)
+    N.check(N.lib().dsvc_pmf_to_quantized_cdf(p.ctypes.data, len(p), precision, out.ctypes.data), "pmf_to_quantized_cdf")
+    return out
+
+
+class RansEncoder:
+    """BufferedRansEncoder (image_model.py:221,253-254)."""
+
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+        N.check(N.lib().dsvc_rans_encoder_create(byref(self.h)), "rans_encoder_create")
+
+    def encode_with_indexes(self, symbols, indexes, tables):
+        s = np.ascontiguousarray(symbols, dtype=np.int32).reshape(-1)
+        i = np.ascontiguousarray(indexes, dtype=np.int32).reshape(-1)
+        assert s.shape == i.shape
+        N.check(N.lib().dsvc_rans_encode_with_indexes(self.h, s.ctypes.data, i.ctypes.data, len(s), byref(tables.c)), "rans_encode")
+
+    def flush(self):
+        L = N.lib()
+        n = N.check(L.dsvc_rans_flush(self.h, None, 0), "rans_flush(size)")
+        buf = ctypes.create_string_buffer(n)
+        N.check(L.dsvc_rans_flush(self.h, buf, n), "rans_flush")
+        return buf.raw
+
+    def __del__(self):
+        try:
+            N.lib().dsvc_rans_encoder_destroy(self.h)
+        except Exception:
+            pass
+
+
+class RansDecoder:
+    """RansDecoder.set_stream + decode_stream (image_model.py:273-274,288)."""
+
+    def __init__(self, data):
+        self.h = ctypes.c_void_p()
+        N.check(N.lib().dsvc_rans_decoder_create(byref(self.h), data, len(data)), "rans_decoder_create")
+
+    def decode_stream(self, indexes, tables):
+        i = np.ascontiguousarray(indexes, dtype=np.int32).reshape(-1)
+        out = np.empty(len(i), dtype=np.int32)
+        N.check(N.lib().dsvc_rans_decode_stream(self.h, i.ctypes.data, len(i), byref(tables.c), out.ctypes.data), "rans_decode")
+        return out
+
+    def __del__(self):
+        try:
+            N.lib().dsvc_rans_decoder_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,72 @@
+"""Synthetic inputs and weight sets for tests and benchmarks.
+
+The reference ships no checkpoints and PyTorch's default init leaves the entropy path degenerate
+(every symbol 0, every scale below the first table level), so parity and throughput are defined on
+*calibrated* synthetic weights:
+
+    W0 = default init of `DeepSVC()` under torch.manual_seed(0)   (CPU generator => same bits on every box)
+         x the per-tensor multipliers committed in deepsvc_amd/data/w0_calibration.json
+         (made by tools/calibrate_w0.py: flow of a few pixels, std(y) ~ 1, std(z) ~ 1, sigma spread over the table).
+    W1 = same recipe under seed 1 ("MS-SSIM" stand-in of BASELINE.json config 4).
+
+Frames: a smooth random texture translating (2,1) px/frame + N(0, 0.01^2) noise, seed 1234;
+semantic feature: relu(N(0,1)) [1,256,H/4,W/4], seed 1234+t.
+"""
+import json
+import os
+
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CALIBRATION = os.path.join(HERE, "data", "w0_calibration.json")
+
+
+def make_frames(H, W, n_frames, seed=1234):
+    """-> list of [1,3,H,W] fp32 CPU tensors in [0,1]."""
+    assert H % 8 == 0 and W % 8 == 0
+    g = torch.Generator().manual_seed(seed)
+    coarse = torch.rand((1, 3, H // 8 + 8, W // 8 + 8), generator=g)
+    base = F.interpolate(coarse, scale_factor=8, mode="bilinear", align_corners=False)
+    frames = []
+    for t in range(n_frames):
+        y0, x0 = 8 + t, 8 + 2 * t
+        noise = torch.randn((1, 3, H, W), generator=g) * 0.01
+        frames.append((base[:, :, y0:y0 + H, x0:x0 + W] + noise).clamp(0.0, 1.0).contiguous())
+    return frames
+
+
+def make_sm_fea(H, W, t, seed=1234):
+    """Stand-in for the semantic layer's output (post-ReLU, semantic_layer.py:1082): [1,256,H/4,W/4]."""
+    g = torch.Generator().manual_seed(seed + t)
+    return torch.relu(torch.randn((1, 256, H // 4, W // 4), generator=g))
+
+
+def load_calibration(path=CALIBRATION):
+    with open(path) as f:
+        return json.load(f)
+
+
+def apply_calibration(state_dict, calib):
+    """calib["tensors"]: key -> {"mul": m, "add": a}: tensor <- tensor * m + a (in place on a copy)."""
+    out = {k: v.clone() for k, v in state_dict.items()}
+    for key, spec in calib["tensors"].items():
+        out[key] = out[key] * float(spec.get("mul", 1.0)) + float(spec.get("add", 0.0))
+    return out
+
+
+def make_model(weight_set="W0", calibrated=True):
+    """Product `DeepSVC` on the CPU with the named synthetic weight set loaded (move it with .to(device))."""
+    from .video_model import DeepSVC
+    seed = {"W0": 0, "W1": 1}[weight_set]
+    rng = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = DeepSVC()
+    torch.random.set_rng_state(rng)
+    if calibrated:
+        sd = apply_calibration(model.state_dict(), load_calibration())
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(sd[k])
+    model.eval()
+    return model

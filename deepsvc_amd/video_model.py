@@ -1,0 +1,151 @@
+"""MI355X-native `DeepSVC` P-frame codec (reference: video_model.py:13-191).
+
+Drop-in for the reference class: same constructor, attribute paths (=> same state_dict keys), and the
+same `forward / forward1 / compress / decompress / update / load_state_dict / aux_loss*` signatures and
+return values, so `test_video.py:230-236,342,349` drives it unchanged.  Underneath, one P-frame is a chain
+of fused HIP launches over NHWC slices; see DESIGN.md section 3 for the dataflow and buffer plan.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+from . import ops
+from .entropy_models import EntropyBottleneck
+from .image_model import ChannelSplitICIP2020ResB
+from .modules import (ME_Spynet, RefineNet, Reconstruction, FeatureExtraction, InterLayerPrediction)
+from .ops import Act, to_act
+
+F32 = torch.float32
+
+
+class DeepSVC(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.opticFlow = ME_Spynet()
+        self.mv_codec = ChannelSplitICIP2020ResB(8, 64, 2)
+        self.res_codec = ChannelSplitICIP2020ResB(64 + 6, 96, 64)
+        self.MC = InterLayerPrediction()
+        self.RefineMvNet = RefineNet(5, 64, 2)
+        self.RefineResiNet = RefineNet(64 + 3, 64, 64)
+        self.FeatureExtractor = FeatureExtraction(3, 64)
+        self.enhance = Reconstruction(32 + 64, 64, 3, return_fea=True)
+
+    # ------------------------------------------------------------------------------------------
+    # stages shared by forward / compress / decompress
+    # ------------------------------------------------------------------------------------------
+    def _feature_in(self, feature):
+        return None if feature is None else to_act(feature, ops.RT.storage)
+
+    def _predict(self, ref, mv_coarse, sm_fea, feature):
+        """mv refine -> warp -> inter-layer prediction (video_model.py:142-144 / 155-158)."""
+        mv = self.RefineMvNet.run(mv_coarse, ref)
+        warped = ops.warp(ref, mv)
+        warp_fea, predict = self.MC.run(ref, warped, mv, sm_fea, feature)
+        return warped, warp_fea, predict
+
+    def _reconstruct(self, ref, predict_fea, res_coarse, warp_fea):
+        """residual refine -> + prediction features -> enhancement (video_model.py:161-165).
+        `predict_fea + recon_res` rides on the refine net's last conv as a second residual."""
+        fea = self.RefineResiNet.run(res_coarse, ref, extra_residual=predict_fea)
+        return self.enhance.run([fea, warp_fea])
+
+    @staticmethod
+    def _bpp(liks, pixels):
+        total = sum(ops.reduce("sumlog", l) for l in liks)
+        return (total / (-math.log(2) * pixels)).to(torch.float32)
+
+    # ------------------------------------------------------------------------------------------
+    # estimate path
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, ref_frame, curr_frame, sm_fea, feature=None):
+        """video_model.py:27-71 -> (recon, feature, mse, warp_mse, mc_mse, bpp_res, bpp_mv, bpp)."""
+        ref, cur = to_act(ref_frame), to_act(curr_frame)
+        pixels = cur.B * cur.H * cur.W
+        mv_est = self.opticFlow.run(cur, ref)
+        mv_coarse, y_lik, z_lik = self.mv_codec.run_forward([cur, mv_est, ref], x_hat_dtype=F32)
+        warped, warp_fea, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
+        bpp_mv = self._bpp([y_lik, z_lik], pixels)
+        predict_fea = self.FeatureExtractor.run(predict)
+        cur_fea = self.FeatureExtractor.run(cur)
+        res = ops.eltwise(N.EW_SUB, cur_fea, predict_fea)
+        res_coarse, y_lik, z_lik = self.res_codec.run_forward([ref, res, predict])
+        bpp_res = self._bpp([y_lik, z_lik], pixels)
+        feat, recon = self._reconstruct(ref, predict_fea, res_coarse, warp_fea)
+        n = float(cur.npix * cur.C)
+        mse = (ops.reduce("sqdiff", recon, cur) / n).to(torch.float32)
+        warp_loss = (ops.reduce("sqdiff", warped, cur) / n).to(torch.float32)
+        mc_loss = (ops.reduce("sqdiff", predict, cur) / n).to(torch.float32)
+        return recon.nchw(), feat.nchw(), mse, warp_loss, mc_loss, bpp_res, bpp_mv, bpp_mv + bpp_res
+
+    @torch.no_grad()
+    def forward1(self, ref_frame, curr_frame, sm_fea, feature=None):
+        """video_model.py:73-94 -> (predict, warp_mse, mc_mse, bpp_mv)."""
+        ref, cur = to_act(ref_frame), to_act(curr_frame)
+        pixels = cur.B * cur.H * cur.W
+        mv_est = self.opticFlow.run(cur, ref)
+        mv_coarse, y_lik, z_lik = self.mv_codec.run_forward([cur, mv_est, ref], x_hat_dtype=F32)
+        warped, _, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
+        n = float(cur.npix * cur.C)
+        return (predict.nchw(), (ops.reduce("sqdiff", warped, cur) / n).to(torch.float32),
+                (ops.reduce("sqdiff", predict, cur) / n).to(torch.float32), self._bpp([y_lik, z_lik], pixels))
+
+    def forward_msssim(self, *args, **kwargs):
+        raise NotImplementedError("forward_msssim (video_model.py:96-135) needs pytorch-msssim's MS-SSIM, which is a "
+                                  "harness metric outside the P-frame hot path (SURVEY.md section 8f-3)")
+
+    # ------------------------------------------------------------------------------------------
+    # real bitstream path
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def compress(self, ref_frame, curr_frame, sm_fea, feature=None):
+        """video_model.py:137-151 -> (mv_out_enc, res_out_enc), each {"strings": [[y],[z...]], "shape": (h,w)}."""
+        ref, cur = to_act(ref_frame), to_act(curr_frame)
+        mv_est = self.opticFlow.run(cur, ref)
+        mv_enc, mv_coarse = self.mv_codec.run_compress([cur, mv_est, ref], want_x_hat=True, x_hat_dtype=F32)
+        _, _, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
+        predict_fea = self.FeatureExtractor.run(predict)
+        cur_fea = self.FeatureExtractor.run(cur)
+        res = ops.eltwise(N.EW_SUB, cur_fea, predict_fea)
+        res_enc, _ = self.res_codec.run_compress([ref, res, predict])
+        return mv_enc, res_enc
+
+    @torch.no_grad()
+    def decompress(self, ref_frame, mv_out_enc, res_out_enc, sm_fea, feature):
+        """video_model.py:153-167 -> (feature, recon, warped, predict), the three frames clamped to [0,1]."""
+        ref = to_act(ref_frame)
+        dev = ref.device
+        mv_coarse = self.mv_codec.run_decompress(mv_out_enc["strings"], mv_out_enc["shape"], dev, x_hat_dtype=F32)
+        warped, warp_fea, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
+        predict_fea = self.FeatureExtractor.run(predict)
+        res_coarse = self.res_codec.run_decompress(res_out_enc["strings"], res_out_enc["shape"], dev)
+        feat, recon = self._reconstruct(ref, predict_fea, res_coarse, warp_fea)
+        clamp = lambda a: ops.eltwise(N.EW_CLAMP01, a).nchw()
+        # `feature` is only ever handed back to the next frame: return it zero-copy in its storage layout/dtype
+        return feat.nchw_view(), clamp(recon), clamp(warped), clamp(predict)
+
+    # ------------------------------------------------------------------------------------------
+    # bookkeeping (same contracts as the reference)
+    # ------------------------------------------------------------------------------------------
+    def aux_loss(self):
+        return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+    def mv_aux_loss(self):
+        return sum(m.loss() for m in self.mv_codec.modules() if isinstance(m, EntropyBottleneck))
+
+    def res_aux_loss(self):
+        return sum(m.loss() for m in self.res_codec.modules() if isinstance(m, EntropyBottleneck))
+
+    def update(self, force=False):
+        updated = self.mv_codec.update(force=force)
+        updated |= self.res_codec.update(force=force)
+        return updated
+
+    def load_state_dict(self, state_dict, strict=True):
+        """video_model.py:184-191: the two codecs first resize their table buffers from their own sub-dicts."""
+        for name in ("mv_codec", "res_codec"):
+            sub = {k[len(name) + 1:]: v for k, v in state_dict.items() if k.startswith(name + ".")}
+            getattr(self, name).load_state_dict(sub, strict=strict)
+        return super().load_state_dict(state_dict, strict=strict)

@@ -1,0 +1,208 @@
+/* dsvc.h -- C ABI of the MI355X-native DeepSVC P-frame hot path (libdsvc.so).
+ *
+ * Boundary contract:
+ *   - plain pointers and sizes only; no torch / C++ types cross this interface;
+ *   - every device pointer is caller-owned HBM (PyTorch owns it in the shipped host layer);
+ *     the library allocates nothing the caller must free except rANS coder handles;
+ *   - every function returns 0 on success or a negative DSVC_E_* code; no exception crosses
+ *     the boundary; dsvc_last_error() returns a thread-local message;
+ *   - device functions are stream-ordered on `stream` (a hipStream_t passed as void*) and do
+ *     not synchronise; host functions (rANS, CDF, packing) are synchronous CPU code.
+ *
+ * Activations are NHWC ("pixel-major"): element (b,y,x,c) of a tensor lives at
+ *   ptr[((b*H + y)*W + x)*ld + c],  ld >= C  (ld > C addresses a channel slice of a wider
+ * buffer: this is how torch.cat / chunk of the reference become zero-copy here).
+ *
+ * Each entry point names the reference interface it replaces (file:line in LHB116/DeepSVC).
+ */
+#ifndef DSVC_H
+#define DSVC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSVC_VERSION 1
+
+/* error codes */
+#define DSVC_OK 0
+#define DSVC_E_ARG (-1)      /* bad argument (shape, alignment, enum) */
+#define DSVC_E_LAUNCH (-2)   /* HIP launch / runtime error */
+#define DSVC_E_RANGE (-3)    /* output buffer too small / stream exhausted */
+#define DSVC_E_PMF (-4)      /* invalid pmf (negative, NaN, zero total) */
+#define DSVC_E_NODEV (-5)    /* no HIP device */
+
+/* element types of activation storage / MFMA compute */
+#define DSVC_F32 0
+#define DSVC_BF16 1
+
+/* fused activations */
+#define DSVC_ACT_NONE 0
+#define DSVC_ACT_RELU 1      /* nn.ReLU                       modules.py:125,180,198 */
+#define DSVC_ACT_LRELU 2     /* nn.LeakyReLU(slope)           modules.py:179,196,238 */
+#define DSVC_ACT_GELU 3      /* nn.GELU() exact erf           image_model.py:86-134  */
+#define DSVC_ACT_SIGMOID 4   /* nn.Sigmoid                    modules.py:333,340,416 */
+#define DSVC_ACT_HALF_TANH 5 /* 0.5*tanh(x)                   image_model.py:187,246,294 */
+
+const char* dsvc_last_error(void);
+int dsvc_version(void);
+/* number of HIP devices visible (0 when none / no driver); never throws */
+int dsvc_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family (one MFMA implicit-GEMM kernel, fused epilogue).
+ * Replaces nn.Conv2d / nn.ConvTranspose2d calls of modules.py:127-131,176-178,200-204,237-242,
+ * 253,307-311,322-340,364,382-418 and image_model.py:25-27,53-146 (compressai conv/deconv/
+ * conv3x3/subpel_conv3x3), together with the pointwise op that follows each of them.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dsvc_seg {
+    const void* ptr; /* channel 0 of pixel (0,0) of image 0 of this input segment */
+    int32_t C;       /* channels taken from this segment */
+    int32_t ld;      /* elements between consecutive pixels */
+    int32_t dtype;   /* DSVC_F32 / DSVC_BF16 */
+} dsvc_seg;
+
+typedef struct dsvc_conv_desc {
+    int32_t B, H, W;      /* input batch / height / width (shared by all segments) */
+    int32_t nseg;         /* 1..3: input = channel-concatenation of the segments (torch.cat) */
+    dsvc_seg in[3];
+    int32_t kh, kw, stride, pad;
+    int32_t Cout;         /* conv output channels (before depth-to-space) */
+    int32_t compute;      /* DSVC_F32: v_mfma_f32_32x32x2_f32; DSVC_BF16: v_mfma_f32_32x32x16_bf16 */
+    const void* weight;   /* device buffer produced by dsvc_conv_pack_weights for this compute type */
+    const float* bias;    /* device [Cout] fp32, or NULL */
+    int32_t pre_act;      /* activation applied to the INPUT while staging (ResBlock1 first_layer) */
+    int32_t act;          /* activation applied to conv+bias */
+    float slope;          /* LeakyReLU slope for pre_act/act */
+    /* out = act(conv+bias) + res1*res1_scale[b][c] + res2   (each optional) */
+    const void* res1; int32_t res1_ld, res1_dtype;
+    const float* res1_scale; /* device [B][Cout] fp32 or NULL (SELayer gate, modules.py:226-230) */
+    const void* res2; int32_t res2_ld, res2_dtype;
+    int32_t shuffle;      /* 1, or r=2: nn.PixelShuffle(2) folded into the store (Cout % 4 == 0) */
+    void* out; int32_t out_ld, out_dtype;
+} dsvc_conv_desc;
+
+/* bytes of the packed weight buffer for a conv with these input segments */
+int64_t dsvc_conv_packed_bytes(int32_t Cout, int32_t nseg, const int32_t* segC, int32_t kh, int32_t kw, int32_t compute);
+/* HOST: OIHW fp32 weights -> packed [chunk][tap][Np][64B] of the compute type (host memory) */
+int dsvc_conv_pack_weights(const float* w_oihw, int32_t Cout, int32_t nseg, const int32_t* segC,
+                           int32_t kh, int32_t kw, int32_t compute, void* packed_host);
+/* HOST: ConvTranspose2d(k=5,s=2,p=2,op=1) weight [Cin][Cout][5][5] (image_model.py:69-81) ->
+ * equivalent 3x3 stride-1 pad-1 conv weight [4*Cout][Cin][3][3] whose output, depth-to-space'd by 2
+ * (channel co*4 + py*2 + px), equals the transposed conv.  bias4 (if given) receives bias repeated. */
+int dsvc_deconv5x5s2_to_conv3x3(const float* w_iohw, const float* bias, int32_t Cin, int32_t Cout,
+                                float* w_oihw_out, float* bias4_out);
+int dsvc_conv2d(void* stream, const dsvc_conv_desc* d);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling / layout kernels (HBM-bound)
+ * ------------------------------------------------------------------------------------------ */
+/* torch_warp (modules.py:25-62): out(b,y,x,:) = bilinear(in, x+flow[..,0], y+flow[..,1]), border clamp.
+ * flow is fp32 NHWC with 2 channels. */
+int dsvc_warp_bilinear_border(void* stream, const void* in, int32_t in_ld, int32_t in_dtype,
+                              const float* flow, int32_t flow_ld, void* out, int32_t out_ld, int32_t out_dtype,
+                              int32_t B, int32_t H, int32_t W, int32_t C);
+/* bilinearupsacling (modules.py:107-112) followed by "* scale" (modules.py:163), fp32 */
+int dsvc_upsample2x_bilinear(void* stream, const float* in, int32_t in_ld, float* out, int32_t out_ld,
+                             int32_t B, int32_t H, int32_t W, int32_t C, float scale);
+/* F.avg_pool2d(2,2) (modules.py:156-157) / nn.MaxPool2d(2,2) (modules.py:260): mode 0 = avg, 1 = max */
+int dsvc_pool2x2(void* stream, int32_t mode, const void* in, int32_t in_ld, void* out, int32_t out_ld,
+                 int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C);
+/* nn.PixelShuffle(r) on an NCHW fp32 source producing NHWC (InterLayerPrediction.d2s, modules.py:391) */
+int dsvc_pixel_shuffle_nchw(void* stream, const float* in_nchw, void* out, int32_t out_ld, int32_t out_dtype,
+                            int32_t B, int32_t Cout, int32_t Hin, int32_t Win, int32_t r);
+/* layout conversion at the API boundary (reference tensors are NCHW fp32) */
+int dsvc_nchw_to_nhwc(void* stream, const float* in, void* out, int32_t out_ld, int32_t out_dtype,
+                      int32_t B, int32_t C, int32_t H, int32_t W);
+int dsvc_nhwc_to_nchw(void* stream, const void* in, int32_t in_ld, int32_t in_dtype, float* out,
+                      int32_t B, int32_t C, int32_t H, int32_t W);
+
+/* ------------------------------------------------------------------------------------------
+ * Pointwise combinations (HBM-bound).  Operands are (ptr, ld, dtype) NHWC slices over n_pix pixels.
+ * ------------------------------------------------------------------------------------------ */
+#define DSVC_EW_COPY 0    /* out = a                                  (torch.cat fall-back)        */
+#define DSVC_EW_ADD 1     /* out = a + b                              video_model.py:62,164        */
+#define DSVC_EW_SUB 2     /* out = a - b                              video_model.py:50,148        */
+#define DSVC_EW_BLEND2 3  /* out = w*a + (1-w)*b                      modules.py:436               */
+#define DSVC_EW_BLEND3 4  /* out = w*a + v*b + (1-w-v)*c  (w=d, v=e)  modules.py:353               */
+#define DSVC_EW_CLAMP01 5 /* out = clamp(a,0,1)                       video_model.py:167           */
+typedef struct dsvc_operand { const void* ptr; int32_t ld; int32_t dtype; } dsvc_operand;
+int dsvc_eltwise(void* stream, int32_t op, int64_t n_pix, int32_t C, const dsvc_operand* a,
+                 const dsvc_operand* b, const dsvc_operand* c, const dsvc_operand* d, const dsvc_operand* e,
+                 void* out, int32_t out_ld, int32_t out_dtype);
+
+/* SELayer (modules.py:217-230): gate[b][c] = sigmoid(W2 relu(W1 mean_hw(x))).  partial is a caller
+ * workspace of at least dsvc_se_workspace_floats(B,C) floats.  Deterministic (no atomics). */
+int64_t dsvc_se_workspace_floats(int32_t B, int32_t C);
+int dsvc_se_gate(void* stream, const void* x, int32_t ld, int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C,
+                 const float* w1 /*[C/r][C]*/, const float* w2 /*[C][C/r]*/, int32_t hidden,
+                 float* partial, float* gate /*[B][C]*/);
+
+/* deterministic reductions into out[0] (fp64 accumulate in the final stage); partial: workspace of
+ * dsvc_reduce_workspace_floats() floats.
+ * mode 0: sum(a)   1: sum(log(a))   2: sum((a-b)^2)   (video_model.py:38-42,46,53-56,68) */
+int64_t dsvc_reduce_workspace_floats(void);
+int dsvc_reduce(void* stream, int32_t mode, int64_t n_pix, int32_t C, const dsvc_operand* a, const dsvc_operand* b,
+                float* partial, double* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Entropy-model arithmetic on device (compressai 1.2.1 semantics)
+ * Symbol / index planes are int32 in the reference's NCHW flattening order [C][h][w]
+ * (image_model.py:241-242: y_q_slice.reshape(-1)).
+ * ------------------------------------------------------------------------------------------ */
+/* GaussianConditional.quantize(y,"symbols",mu) + build_indexes(scale) + y_hat = q + mu
+ * (image_model.py:237-239).  y/mu/scale/y_hat are NHWC slices; table = 64 fp32 scale levels (device).
+ * symbols/indexes/y_hat may each be NULL to skip. */
+int dsvc_gc_quantize(void* stream, const void* y, int32_t y_ld, const void* mu, int32_t mu_ld,
+                     const void* scale, int32_t scale_ld, int32_t dtype, const float* table, int32_t levels,
+                     int32_t B, int32_t H, int32_t W, int32_t C,
+                     int32_t* symbols, int32_t* indexes, void* y_hat, int32_t y_hat_ld);
+/* GaussianConditional.dequantize (image_model.py:290): y_hat = float(symbols) + mu */
+int dsvc_gc_dequantize(void* stream, const int32_t* symbols, const void* mu, int32_t mu_ld, int32_t dtype,
+                       int32_t B, int32_t H, int32_t W, int32_t C, void* y_hat, int32_t y_hat_ld);
+/* GaussianConditional.forward eval (image_model.py:181): y_hat = round(y-mu)+mu,
+ * lik = max(Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), 1e-9), s = max(scale, 0.11); lik fp32 NHWC */
+int dsvc_gc_likelihood(void* stream, const void* y, int32_t y_ld, const void* mu, int32_t mu_ld,
+                       const void* scale, int32_t scale_ld, int32_t dtype, int64_t n_pix, int32_t C,
+                       void* y_hat, int32_t y_hat_ld, float* lik, int32_t lik_ld);
+/* EntropyBottleneck (image_model.py:155-162,206-207,260).  params: device fp32 blob per channel
+ * [C][59] = matrices(3,9,9,9,3) biases(3,3,3,3,1) factors(3,3,3,3) median(1), already softplus'd /
+ * tanh'd on the host.  mode bit0: write symbols (int32 planar [C][h][w]); bit1: write z_hat;
+ * bit2: write likelihood (fp32 NHWC). */
+#define DSVC_EB_PARAMS_PER_CH 59
+int dsvc_eb_process(void* stream, const void* z, int32_t z_ld, int32_t dtype, const float* params,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode,
+                    int32_t* symbols, void* z_hat, int32_t z_hat_ld, float* lik, int32_t lik_ld);
+/* z_hat = float(symbols) + median  (EntropyBottleneck.decompress -> dequantize) */
+int dsvc_eb_dequantize(void* stream, const int32_t* symbols, const float* params, int32_t dtype,
+                       int32_t B, int32_t H, int32_t W, int32_t C, void* z_hat, int32_t z_hat_ld);
+
+/* ------------------------------------------------------------------------------------------
+ * HOST: integer CDF construction and the range coder (compressai 1.2.1 _CXX / ans; Appendix A.4/A.5)
+ * ------------------------------------------------------------------------------------------ */
+/* _CXX.pmf_to_quantized_cdf: pmf float[n] -> cdf int32[n+1] */
+int dsvc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf);
+
+typedef struct dsvc_cdf_table {
+    const int32_t* cdf;     /* [rows][stride] */
+    int32_t rows, stride;
+    const int32_t* cdf_length; /* [rows] */
+    const int32_t* offset;     /* [rows] */
+} dsvc_cdf_table;
+
+/* BufferedRansEncoder (image_model.py:221,253-254) */
+int dsvc_rans_encoder_create(void** enc);
+void dsvc_rans_encoder_destroy(void* enc);
+int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, const int32_t* indexes, int64_t n,
+                                  const dsvc_cdf_table* t);
+/* flush(): returns the byte count; if out==NULL only queries; encoder is reset after a successful copy */
+int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap);
+/* RansDecoder (image_model.py:273-274,288); the stream bytes are copied */
+int dsvc_rans_decoder_create(void** dec, const uint8_t* data, int64_t nbytes);
+void dsvc_rans_decoder_destroy(void* dec);
+int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_t n, const dsvc_cdf_table* t, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSVC_H */
