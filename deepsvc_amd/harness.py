@@ -1,0 +1,85 @@
+"""GOP loop, metrics and multi-GPU sharding around the P-frame codec -- the build's counterpart of the part of
+the reference's evaluation script that drives the hot path (test_video.py:290-369, 353-366).
+
+One process per GPU; the unit of work is a (sequence, GOP): P-frame t needs `ref_frame` and `feature` of t-1
+(test_video.py:368-369) and every key frame resets both (:296-297,332), so GOPs are independent and shard across
+ranks with NO data-path collective.  The only communication is one gather of per-frame metric rows at the end
+(RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
+"""
+import math
+import time
+
+import torch
+import torch.nn.functional as F
+
+from .modules import crop, pad
+
+METRIC_COLUMNS = ("unit", "frame", "bpp_mv", "bpp_res", "psnr", "psnr_mc", "psnr_warp", "t_enc", "t_dec")
+
+
+def shard_units(n_units, rank, world_size):
+    """Static round-robin assignment of GOP indices to ranks."""
+    return list(range(rank, n_units, world_size))
+
+
+def strings_bytes(enc):
+    """test_video.py:364-365."""
+    return sum(len(s[0]) for s in enc["strings"])
+
+
+def _psnr(a, b):
+    mse = F.mse_loss(a, b).item()
+    return 99.0 if mse <= 0 else -10.0 * math.log10(mse)
+
+
+def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True):
+    """Encode+decode one GOP.  frames[0] is the (already decoded) key frame, frames[1:] are P-frames; all are
+    [1,3,h,w] tensors on the model's device, un-padded.  Returns one metric row per P-frame."""
+    sync = sync or (lambda: None)
+    h, w = frames[0].shape[-2:]
+    ref = pad(frames[0], 64)
+    feature = None
+    rows = []
+    for t in range(1, len(frames)):
+        cur = pad(frames[t], 64)
+        sm = sm_feas[t]
+        sync(); t0 = time.perf_counter()
+        mv_enc, res_enc = model.compress(ref, cur, sm, feature)
+        sync(); t1 = time.perf_counter()
+        feature, recon, warped, predict = model.decompress(ref, mv_enc, res_enc, sm, feature)
+        sync(); t2 = time.perf_counter()
+        row = [float(unit), float(t), strings_bytes(mv_enc) * 8.0 / (h * w), strings_bytes(res_enc) * 8.0 / (h * w)]
+        if metrics:
+            org = frames[t]
+            row += [_psnr(crop(recon, (h, w)), org), _psnr(crop(predict, (h, w)), org), _psnr(crop(warped, (h, w)), org)]
+        else:
+            row += [0.0, 0.0, 0.0]
+        rows.append(row + [t1 - t0, t2 - t1])
+        ref = recon
+    return rows
+
+
+def gather_rows(rows, device, world_size):
+    """All ranks' metric rows -> one [n, len(METRIC_COLUMNS)] fp64 CPU tensor on every rank."""
+    local = torch.tensor(rows, dtype=torch.float64, device=device).reshape(-1, len(METRIC_COLUMNS))
+    if world_size == 1:
+        return local.cpu()
+    import torch.distributed as dist
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world_size)]
+    dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=device))
+    n_max = int(max(int(c) for c in counts))
+    padded = torch.zeros((n_max, local.shape[1]), dtype=torch.float64, device=device)
+    padded[: local.shape[0]] = local
+    parts = [torch.zeros_like(padded) for _ in range(world_size)]
+    dist.all_gather(parts, padded)
+    return torch.cat([p[: int(c)] for p, c in zip(parts, counts)], 0).cpu()
+
+
+def summarise(table):
+    cols = {n: table[:, i] for i, n in enumerate(METRIC_COLUMNS)}
+    n = table.shape[0]
+    return {"frames": int(n), "bpp": float((cols["bpp_mv"] + cols["bpp_res"]).mean()) if n else 0.0,
+            "mvbpp": float(cols["bpp_mv"].mean()) if n else 0.0, "resbpp": float(cols["bpp_res"].mean()) if n else 0.0,
+            "ppsnr": float(cols["psnr"].mean()) if n else 0.0, "mcpsnr": float(cols["psnr_mc"].mean()) if n else 0.0,
+            "warppsnr": float(cols["psnr_warp"].mean()) if n else 0.0,
+            "pent": float(cols["t_enc"].mean()) if n else 0.0, "pdec": float(cols["t_dec"].mean()) if n else 0.0}

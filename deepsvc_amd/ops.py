@@ -156,6 +156,11 @@ def deconv_as_conv_weights(w_iohw, bias):
     return wo, bo
 
 
+# Optional per-launch timing of selected conv launches with HIP events recorded on the launch stream
+# (bench.py's roofline leg): {"match": fn(pc, x0) -> bool, "pairs": [(start_event, end_event), ...]}
+PROFILE = None
+
+
 def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.01, res1=None, gate=None, res2=None,
            shuffle=1, out_dtype=None):
     """Run one fused conv.  inputs: list of Act (virtual torch.cat along channels)."""
@@ -191,6 +196,14 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
         d.res2, d.res2_ld, d.res2_dtype = res2.ptr, res2.ld, res2.code
     d.shuffle = shuffle
     d.out, d.out_ld, d.out_dtype = out.ptr, out.ld, out.code
+    prof = PROFILE
+    if prof is not None and prof["match"](pc, x0):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
+        e1.record()
+        prof["pairs"].append((e0, e1))
+        return out
     N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
     return out
 

@@ -1,0 +1,151 @@
+"""CPU-side checks of the product library: it loads without a GPU, exports every symbol include/dsvc.h declares,
+and its HOST functions (range coder, CDF construction, weight packing) agree with the oracle.
+No device kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deepsvc_amd import _native as N
+from deepsvc_amd import ops
+from oracle import entropy as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "dsvc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsvc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 30
+    L = N.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/dsvc.h but not exported by libdsvc.so"
+        assert n in N.SIGNATURES, f"{n} has no ctypes signature in deepsvc_amd/_native.py"
+    assert set(N.SIGNATURES) == set(names)
+    assert L.dsvc_version() == 1
+
+
+def test_cpu_tensors_are_refused():
+    from deepsvc_amd.modules import Conv2d, torch_warp
+    with pytest.raises(N.NativeError):
+        Conv2d(3, 8, 3, 1, 1)(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(N.NativeError):
+        torch_warp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+
+
+def test_error_convention():
+    L = N.lib()
+    assert L.dsvc_conv2d(None, None) == -1
+    assert b"null descriptor" in L.dsvc_last_error()
+    with pytest.raises(N.NativeError):
+        ops.pmf_to_quantized_cdf(np.array([0.5, -1.0], dtype=np.float32))
+    with pytest.raises(N.NativeError):
+        ops.RansDecoder(b"\x00\x01\x02")
+
+
+@pytest.fixture(scope="module")
+def gc():
+    return E.gc_tables()
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 1000, 60000])
+def test_rans_bytes_equal_oracle(gc, n):
+    rng = np.random.default_rng(n)
+    idx = rng.integers(0, 64, n).astype(np.int32)
+    sym = np.round(rng.standard_normal(n) * gc["scale_table"].numpy()[idx] * 1.3).astype(np.int32)
+    if n > 10:
+        sym[::9] += 123456
+        sym[4::9] -= 654321
+    t = ops.CdfTables(gc["cdf"], gc["cdf_length"], gc["offset"])
+    enc = ops.RansEncoder()
+    k = n // 2          # two encode calls accumulate into one stream (BufferedRansEncoder)
+    enc.encode_with_indexes(sym[:k], idx[:k], t)
+    enc.encode_with_indexes(sym[k:], idx[k:], t)
+    data = enc.flush()
+    assert data == E.rans_encode(sym, idx, gc["cdf"], gc["cdf_length"], gc["offset"])
+    dec = ops.RansDecoder(data)
+    out = np.concatenate([dec.decode_stream(idx[:k], t), dec.decode_stream(idx[k:], t)])
+    assert np.array_equal(out, sym)
+    # the oracle decodes the product's stream too
+    assert np.array_equal(E.RansDecoder(data).decode(idx, gc["cdf"], gc["cdf_length"], gc["offset"]), sym)
+
+
+def test_pmf_to_quantized_cdf_equals_oracle():
+    rng = np.random.default_rng(7)
+    for n in (2, 5, 64, 777):
+        p = (rng.random(n) ** 10).astype(np.float32)
+        p /= p.sum()
+        assert np.array_equal(ops.pmf_to_quantized_cdf(p), E.pmf_to_quantized_cdf(p))
+
+
+def test_entropy_model_tables_equal_oracle():
+    from deepsvc_amd.entropy_models import EntropyBottleneck, GaussianConditional
+    from deepsvc_amd.modules import get_scale_table
+    torch.manual_seed(11)
+    eb = EntropyBottleneck(8)
+    with torch.no_grad():
+        eb.quantiles[:, 0, 0] -= torch.rand(8) * 5
+        eb.quantiles[:, 0, 2] += torch.rand(8) * 7
+        eb._matrix1 += torch.randn_like(eb._matrix1) * 0.1
+    assert eb.update() and not eb.update()
+    t = E.eb_tables({k: v.detach() for k, v in eb.state_dict().items()}, "")
+    assert np.array_equal(eb.quantized_cdf.numpy(), t["cdf"])
+    assert np.array_equal(eb.cdf_length.numpy(), t["cdf_length"]) and np.array_equal(eb.offset.numpy(), t["offset"])
+    g = GaussianConditional(None)
+    assert g.update_scale_table(get_scale_table())
+    o = E.gc_tables()
+    assert np.array_equal(g.quantized_cdf.numpy(), o["cdf"]) and np.array_equal(g.offset.numpy(), o["offset"])
+    assert np.array_equal(g.cdf_length.numpy(), o["cdf_length"])
+    assert torch.equal(g.scale_table, o["scale_table"])
+
+
+def test_deconv_rewrite_is_exact():
+    """ConvTranspose2d(5,s2,p2,op1) == PixelShuffle(2)(conv3x3 with the rewritten weights) -- checked with torch-CPU."""
+    torch.manual_seed(0)
+    w, b = torch.randn(5, 3, 5, 5), torch.randn(3)
+    w3, b4 = ops.deconv_as_conv_weights(w, b)
+    x = torch.randn(2, 5, 6, 7)
+    want = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
+    got = F.pixel_shuffle(F.conv2d(x, w3, b4, padding=1), 2)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("compute", [N.F32, N.BF16])
+def test_weight_packing_layout(compute):
+    """[chunk][tap][Np][64 B]; chunks never straddle segments; zero padded."""
+    torch.manual_seed(1)
+    segs, cout, k = (5, 20), 6, 3
+    w = torch.randn(cout, sum(segs), k, k)
+    pc = ops.PackedConv.__new__(ops.PackedConv)
+    import ctypes
+    sa = (ctypes.c_int32 * 2)(*segs)
+    nb = N.lib().dsvc_conv_packed_bytes(cout, 2, sa, k, k, compute)
+    kce = 16 if compute == N.F32 else 32
+    nch = sum(-(-c // kce) for c in segs)
+    assert nb == nch * 9 * 32 * 64
+    host = np.empty(nb, np.uint8)
+    assert N.lib().dsvc_conv_pack_weights(w.contiguous().data_ptr(), cout, 2, sa, k, k, compute, host.ctypes.data) == 0
+    if compute == N.F32:
+        arr = host.view(np.float32).reshape(nch, 9, 32, 16)
+        ref = w.numpy()
+    else:
+        arr = (host.view(np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(nch, 9, 32, 32)
+        ref = w.to(torch.bfloat16).float().numpy()
+    chunk, cbase = 0, 0
+    for c in segs:
+        for j in range(-(-c // kce)):
+            for e in range(kce):
+                cl = j * kce + e
+                for n in range(32):
+                    want = ref[n, cbase + cl].reshape(9) if (n < cout and cl < c) else np.zeros(9, np.float32)
+                    assert np.array_equal(arr[chunk, :, n, e], want)
+            chunk += 1
+        cbase += c

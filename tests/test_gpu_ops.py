@@ -1,0 +1,238 @@
+"""GPU parity of every HIP op, called through the C ABI (deepsvc_amd.ops), against plain PyTorch-CPU fp32
+(or the oracle's restatement) on the same seeded inputs.  Tolerances: fp32 MFMA path 1e-4 relative to the
+output scale; bf16 MFMA path is compared with a reference fed the same bf16-rounded operands (5e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import report_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from deepsvc_amd import _native
+    assert _native.lib().dsvc_device_count() >= 1
+    from deepsvc_amd import ops
+    ops.set_precision("fp32")
+    yield
+    ops.set_precision("fp32")
+
+
+def _act(x, dtype=torch.float32):
+    from deepsvc_amd import ops
+    return ops.to_act(x.to(DEV), dtype)
+
+
+def _torch_act(v, code, slope=0.01):
+    from deepsvc_amd import _native as N
+    return {N.ACT_NONE: lambda t: t, N.ACT_RELU: F.relu, N.ACT_LRELU: lambda t: F.leaky_relu(t, slope),
+            N.ACT_GELU: F.gelu, N.ACT_SIGMOID: torch.sigmoid, N.ACT_HALF_TANH: lambda t: 0.5 * torch.tanh(t)}[code](v)
+
+
+CONV_CASES = [
+    # (segments, Cout, k, stride, H, W)
+    ((64,), 64, 3, 1, 20, 37), ((64,), 64, 3, 1, 8, 32), ((3,), 64, 3, 1, 17, 33), ((5,), 64, 3, 1, 9, 40),
+    ((64, 3), 64, 3, 1, 12, 34), ((96,), 96, 3, 1, 10, 31), ((128,), 128, 3, 1, 9, 33), ((64,), 3, 3, 1, 21, 35),
+    ((64,), 2, 3, 1, 8, 8), ((16,), 64, 3, 1, 1, 1), ((32,), 3, 3, 1, 40, 70), ((64, 64), 64, 3, 1, 11, 30),
+    ((3, 64, 3), 96, 5, 2, 32, 48), ((3, 2, 3), 64, 5, 2, 16, 64), ((96,), 96, 5, 2, 8, 12), ((64,), 64, 3, 2, 8, 14),
+    ((8,), 32, 7, 1, 9, 35), ((32,), 64, 7, 1, 12, 20), ((16,), 2, 7, 1, 16, 33), ((64,), 64, 1, 1, 13, 29),
+    ((128,), 256, 1, 1, 6, 10), ((64, 24, 8), 64, 3, 1, 5, 9), ((96, 48), 96, 3, 1, 4, 8), ((156,), 96, 3, 1, 4, 30),
+    ((64,), 8, 3, 1, 4, 8), ((32,), 12, 3, 1, 5, 7), ((64,), 128, 1, 1, 7, 9),
+]
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{'+'.join(map(str, c[0]))}to{c[1]}_k{c[2]}s{c[3]}_{c[4]}x{c[5]}")
+def test_conv_plain(case, compute):
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    segs, cout, k, s, H, W = case
+    torch.manual_seed(hash(case) & 0xFFFF)
+    ops.set_precision(compute)
+    try:
+        m = Conv2d(sum(segs), cout, k, s, padding=k // 2)
+        xs = [torch.randn(2, c, H, W) for c in segs]
+        got = m.to(DEV).run([_act(x) for x in xs], out_dtype=torch.float32).nchw().cpu()
+    finally:
+        ops.set_precision("fp32")
+    x, w = torch.cat(xs, 1), m.weight.detach().cpu()
+    if compute == "bf16":
+        x, w = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    want = F.conv2d(x, w, m.bias.detach().cpu(), stride=s, padding=k // 2)
+    tol = 2e-4 if compute == "fp32" else 5e-3
+    report_close(f"conv {case} {compute}", got, want, tol, tol * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4, 5])
+def test_conv_epilogue_activations(act):
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(act)
+    m = Conv2d(24, 40, 3, 1, 1)
+    x, r1, r2 = torch.randn(1, 24, 13, 37), torch.randn(1, 40, 13, 37), torch.randn(1, 40, 13, 37)
+    gate = torch.rand(1, 40)
+    got = m.to(DEV).run(_act(x), act=act, pre_act=2, slope=0.2, res1=_act(r1), gate=gate.to(DEV), res2=_act(r2)).nchw().cpu()
+    want = _torch_act(F.conv2d(F.leaky_relu(x, 0.2), m.weight.cpu(), m.bias.cpu(), padding=1), act, 0.2) + gate[:, :, None, None] * r1 + r2
+    report_close(f"epilogue act={act}", got, want, 2e-4, 2e-4)
+
+
+def test_conv_slices_shuffle_and_bf16_storage():
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d, Deconv5x5s2, _SubpelConv
+    torch.manual_seed(5)
+    # input read from / output written into channel slices of wider buffers
+    big_in = torch.randn(1, 40, 9, 33)
+    a = _act(big_in)
+    m = Conv2d(16, 20, 3, 1, 1).to(DEV)
+    out_buf = ops.new_act(1, 9, 33, 50, torch.float32, DEV)
+    out_buf.buf.fill_(7.0)
+    m.run(a.ch(8, 16), out_buf.ch(10, 20))
+    full = out_buf.nchw().cpu()
+    want = F.conv2d(big_in[:, 8:24], m.weight.cpu(), m.bias.cpu(), padding=1)
+    report_close("slice conv", full[:, 10:30], want, 2e-4, 2e-4)
+    assert bool((full[:, :10] == 7).all()) and bool((full[:, 30:] == 7).all()), "conv wrote outside its channel slice"
+    # sub-pixel conv (PixelShuffle folded into the store) + GELU
+    sp = _SubpelConv(12, 6, 2, 3).to(DEV)
+    x = torch.randn(2, 12, 7, 11)
+    got = sp.run(_act(x), act=3).nchw().cpu()
+    want = F.gelu(F.pixel_shuffle(F.conv2d(x, sp[0].weight.cpu(), sp[0].bias.cpu(), padding=1), 2))
+    report_close("subpel", got, want, 2e-4, 2e-4)
+    # transposed conv as 4-phase conv
+    d = Deconv5x5s2(10, 6).to(DEV)
+    x = torch.randn(1, 10, 6, 9)
+    want = F.conv_transpose2d(x, d.weight.cpu(), d.bias.cpu(), stride=2, padding=2, output_padding=1)
+    report_close("deconv", d.run(_act(x)).nchw().cpu(), want, 2e-4, 2e-4)
+    # bf16 activation storage in and out
+    x = torch.randn(1, 32, 10, 34)
+    mm = Conv2d(32, 32, 3, 1, 1).to(DEV)
+    res = torch.randn(1, 32, 10, 34)
+    got = mm.run(_act(x, torch.bfloat16), res1=_act(res, torch.bfloat16), out_dtype=torch.bfloat16)
+    assert got.dtype == torch.bfloat16
+    want = F.conv2d(x.to(torch.bfloat16).float(), mm.weight.cpu(), mm.bias.cpu(), padding=1) + res.to(torch.bfloat16).float()
+    report_close("bf16 storage", got.nchw().cpu(), want, 1e-2, 1e-2)
+
+
+def test_warp_matches_grid_sample():
+    from deepsvc_amd import ops
+    from oracle import nets
+    torch.manual_seed(0)
+    for C, H, W in ((3, 16, 24), (64, 9, 13), (5, 8, 8)):
+        x = torch.randn(2, C, H, W)
+        flow = torch.randn(2, 2, H, W) * 4
+        flow[0, :, 0, 0] = torch.tensor([-100.0, 50.0])      # far outside: border clamp
+        flow[1, :, 1, 1] = torch.tensor([0.0, 0.0])
+        got = ops.warp(_act(x), _act(flow)).nchw().cpu()
+        report_close(f"warp C={C}", got, nets.warp(x, flow), 1e-4, 2e-4)
+
+
+def test_resampling_and_layout_ops():
+    from deepsvc_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(2, 2, 5, 7)
+    report_close("upsample2x", ops.upsample2x(_act(x), 2.0).nchw().cpu(),
+                 F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) * 2.0, 1e-5, 1e-5)
+    x = torch.randn(1, 3, 8, 12)
+    report_close("avgpool", ops.pool2x2(_act(x), "avg").nchw().cpu(), F.avg_pool2d(x, 2, 2), 1e-6, 1e-6)
+    x = torch.randn(2, 32, 6, 10)
+    report_close("maxpool", ops.pool2x2(_act(x), "max").nchw().cpu(), F.max_pool2d(x, 2, 2), 0, 0)
+    x = torch.randn(2, 64, 5, 6)
+    report_close("pixel_shuffle4", ops.pixel_shuffle_nchw(x.to(DEV), 4, dtype=torch.float32).nchw().cpu(), F.pixel_shuffle(x, 4), 0, 0)
+    x = torch.randn(2, 37, 9, 11)       # NCHW-contiguous input goes through the transpose kernel
+    a = ops.to_act(x.to(DEV))
+    assert torch.equal(a.buf.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    b16 = ops.to_act(x.to(DEV), torch.bfloat16)
+    assert torch.equal(b16.nchw().cpu(), x.to(torch.bfloat16).float())
+    xc = x.to(DEV).contiguous(memory_format=torch.channels_last)   # channels_last input is taken zero-copy
+    assert ops.to_act(xc).buf.data_ptr() == xc.data_ptr()
+
+
+def test_pointwise_and_reductions():
+    from deepsvc_amd import _native as N, ops
+    torch.manual_seed(2)
+    a, b, c = (torch.randn(1, 3, 9, 10) for _ in range(3))
+    w, v = torch.rand(1, 3, 9, 10), torch.rand(1, 3, 9, 10)
+    A, B, C, Wt, V = map(_act, (a, b, c, w, v))
+    report_close("add", ops.eltwise(N.EW_ADD, A, B).nchw().cpu(), a + b, 1e-6, 1e-6)
+    report_close("sub", ops.eltwise(N.EW_SUB, A, B).nchw().cpu(), a - b, 1e-6, 1e-6)
+    report_close("blend2", ops.eltwise(N.EW_BLEND2, A, B, d=Wt).nchw().cpu(), w * a + (1 - w) * b, 1e-6, 1e-6)
+    report_close("blend3", ops.eltwise(N.EW_BLEND3, A, B, C, Wt, V).nchw().cpu(), w * a + v * b + (1 - w - v) * c, 1e-6, 1e-6)
+    report_close("clamp", ops.eltwise(N.EW_CLAMP01, A).nchw().cpu(), a.clamp(0, 1), 0, 0)
+    x = torch.rand(2, 5, 33, 17) + 0.01
+    y = torch.rand(2, 5, 33, 17)
+    X, Y = _act(x), _act(y)
+    np.testing.assert_allclose(float(ops.reduce("sum", X)), float(x.double().sum()), rtol=1e-6)
+    np.testing.assert_allclose(float(ops.reduce("sumlog", X)), float(x.double().log().sum()), rtol=1e-5)
+    np.testing.assert_allclose(float(ops.reduce("sqdiff", X, Y)), float(((x - y).double() ** 2).sum()), rtol=1e-5)
+    r1, r2 = ops.reduce("sumlog", X), ops.reduce("sumlog", X)
+    assert float(r1) == float(r2), "reduction must be run-to-run deterministic"
+
+
+def test_se_gate():
+    from deepsvc_amd.modules import SELayer
+    from oracle import nets
+    torch.manual_seed(3)
+    for C in (32, 64, 128):
+        se = SELayer(C)
+        x = torch.randn(2, C, 19, 23)
+        sd = {"fc.0.weight": se.fc[0].weight.detach(), "fc.2.weight": se.fc[2].weight.detach()}
+        want = nets.se_layer(nets.P(sd), x)
+        se = se.to(DEV)
+        g = se.gate(_act(x)).cpu()
+        report_close(f"se gate C={C}", g[:, :, None, None] * x, want, 1e-5, 1e-5)
+
+
+def test_gaussian_conditional_kernels():
+    from deepsvc_amd import ops
+    from oracle import entropy as E
+    torch.manual_seed(4)
+    gc = E.gc_tables()
+    table = gc["scale_table"]
+    B, C, H, W = 2, 12, 7, 9
+    y, mu = torch.randn(B, C, H, W) * 3, torch.randn(B, C, H, W)
+    sc = torch.exp(torch.randn(B, C, H, W) * 2 - 1)
+    sc[0, 0, 0, :] = table[:9]            # exactly on table levels (the <= comparison)
+    sc[0, 1, 0, 0], sc[0, 1, 0, 1] = -1.0, 1e6
+    y[0, 2, 0, 0], mu[0, 2, 0, 0] = 2.5, 0.0   # round-half-to-even
+    y[0, 2, 0, 1], mu[0, 2, 0, 1] = 3.5, 0.0
+    Y, MU, SC = _act(y), _act(mu), _act(sc)
+    yh = ops.new_act(B, H, W, C, torch.float32, DEV)
+    sym, idx = ops.gc_quantize(Y, MU, SC, table.to(DEV), True, True, yh)
+    want_sym = torch.round(y - mu).int()
+    assert torch.equal(sym.cpu().view(B, C, H, W), want_sym)
+    assert torch.equal(idx.cpu().view(B, C, H, W), E.gc_build_indexes(sc, table))
+    assert torch.equal(yh.nchw().cpu(), want_sym.float() + mu)
+    yh2 = ops.new_act(B, H, W, C, torch.float32, DEV)
+    ops.gc_dequantize(sym, MU, yh2)
+    assert torch.equal(yh2.nchw().cpu(), want_sym.float() + mu)
+    lik = ops.new_act(B, H, W, C, torch.float32, DEV)
+    ops.gc_likelihood(Y, MU, SC, None, lik)
+    _, want_lik = E.gc_forward(y, sc, mu)
+    report_close("gc likelihood", lik.nchw().cpu(), want_lik, 2e-4, 1e-7)
+
+
+def test_entropy_bottleneck_kernels():
+    from deepsvc_amd.entropy_models import EntropyBottleneck
+    from oracle import entropy as E
+    torch.manual_seed(6)
+    eb = EntropyBottleneck(10)
+    with torch.no_grad():
+        for n, p in eb.named_parameters():
+            if n != "quantiles":
+                p.add_(torch.randn_like(p) * 0.2)
+        eb.quantiles[:, 0, 1] += torch.randn(10)
+    sd = {k: v.detach().clone() for k, v in eb.state_dict().items()}
+    eb.update()
+    eb = eb.to(DEV)
+    z = torch.randn(2, 10, 5, 6) * 4
+    zh_want, lik_want = E.eb_forward(sd, "", z)
+    zh, lik = eb(z.to(DEV))
+    report_close("eb z_hat", zh.cpu(), zh_want, 0, 1e-6)
+    report_close("eb likelihood", lik.cpu(), lik_want, 5e-4, 1e-7)
+    strings = eb.compress(z.to(DEV))
+    assert strings == E.eb_compress(sd, "", E.eb_tables(sd, ""), z)
+    report_close("eb decompress", eb.decompress(strings, (5, 6)).cpu(), zh_want, 0, 1e-6)

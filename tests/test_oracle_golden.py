@@ -1,0 +1,109 @@
+"""The oracle (CPU restatement) against golden vectors produced by the REFERENCE itself
+(tests/golden/make_golden.py).  This is what pins rows a1-a15 of SURVEY.md section 8."""
+import numpy as np
+import pytest
+import torch
+
+from deepsvc_amd import synth
+from oracle.codec import strings_nbytes
+
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def _expect(g, key):
+    return g[key + "/data"], tuple(g[key + "/shape"]), g[key + "/stats"]
+
+
+def _check(g, key, t, tol=TOL):
+    data, shape, stats = _expect(g, key)
+    a = t.detach().float().numpy()
+    assert tuple(a.shape) == shape, key
+    sub = a if a.size <= 16384 else a[..., ::4, ::4]
+    np.testing.assert_allclose(sub, data, err_msg=key, **tol)
+    np.testing.assert_allclose(a.astype(np.float64).sum(), stats[0], rtol=1e-3, atol=1e-2, err_msg=key + " sum")
+    np.testing.assert_allclose((a.astype(np.float64) ** 2).sum(), stats[1], rtol=1e-3, atol=1e-3, err_msg=key + " sumsq")
+
+
+def _inputs(size, steady, g=None, tag=None, oracle=None):
+    frames = synth.make_frames(size, size, 3)
+    if not steady:
+        return frames[0], frames[1], synth.make_sm_fea(size, size, 1), None
+    sm1 = synth.make_sm_fea(size, size, 1)
+    mv, res = oracle.compress(frames[0], frames[1], sm1, None)
+    feat, recon, _, _ = oracle.decompress(frames[0], mv, res, sm1, None)
+    return recon, frames[2], synth.make_sm_fea(size, size, 2), feat
+
+
+@pytest.mark.parametrize("tag,steady", [("s64_first", False), ("s64_steady", True)])
+def test_forward_stages_match_reference(golden64, oracle_w0, tag, steady):
+    g = golden64
+    ref, cur, sm, feat = _inputs(64, steady, oracle=oracle_w0)
+    if steady:  # the chained state itself must match what the reference produced
+        _check(g, f"{tag}/in/ref_frame", ref)
+        _check(g, f"{tag}/in/feature", feat)
+    taps = {}
+    out = oracle_w0.forward(ref, cur, sm, feat, taps=taps)
+    pre = f"{tag}/fwd/"
+    _check(g, pre + "opticFlow#0@0", taps["mv_est"])
+    _check(g, pre + "mv_codec.g_a#0@0", taps["mv"]["y"])
+    _check(g, pre + "mv_codec.h_a#0@0", taps["mv"]["z"])
+    _check(g, pre + "mv_codec.h_mean_s#0@0", taps["mv"]["latent_means"])
+    _check(g, pre + "mv_codec.h_scale_s#0@0", taps["mv"]["latent_scales"])
+    for i in (0, 3, 4, 7):
+        _check(g, pre + f"mv_codec.cc_mean_transforms.{i}#0@0", taps["mv"]["mu"][i])
+        _check(g, pre + f"mv_codec.cc_scale_transforms.{i}#0@0", taps["mv"]["scale"][i])
+        _check(g, pre + f"res_codec.cc_mean_transforms.{i}#0@0", taps["res"]["mu"][i])
+        _check(g, pre + f"res_codec.cc_scale_transforms.{i}#0@0", taps["res"]["scale"][i])
+    _check(g, pre + "mv_codec.g_s#0@0", taps["recon_mv1"])
+    _check(g, pre + "RefineMvNet#0@0", taps["recon_mv"])
+    _check(g, pre + "MC#0@0", taps["warp_fea"])
+    _check(g, pre + "MC#1@0", taps["predict"])
+    _check(g, pre + "FeatureExtractor#0@0", taps["predict_fea"])
+    _check(g, pre + "FeatureExtractor#0@1", taps["cur_fea"])
+    _check(g, pre + "res_codec.g_a#0@0", taps["res"]["y"])
+    _check(g, pre + "res_codec.g_s#0@0", taps["recon_res1"])
+    _check(g, pre + "RefineResiNet#0@0", taps["recon_res"])
+    _check(g, pre + "enhance#0@0", taps["feature"])
+    _check(g, pre + "enhance#1@0", taps["recon"])
+    _check(g, pre + "out_recon", out[0])
+    _check(g, pre + "out_feature", out[1])
+    np.testing.assert_allclose([float(v) for v in out[2:]], g[pre + "scalars"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("size,tag,steady", [(64, "s64_first", False), (64, "s64_steady", True), (128, "s128_steady", True)])
+def test_compress_decompress_match_reference(golden64, golden128, oracle_w0, size, tag, steady):
+    g = golden64 if size == 64 else golden128
+    ref, cur, sm, feat = _inputs(size, steady, oracle=oracle_w0)
+    mv, res = oracle_w0.compress(ref, cur, sm, feat)
+    for nm, enc in (("mv", mv), ("res", res)):
+        assert enc["strings"][0][0] == g[f"{tag}/enc/{nm}_y"].tobytes(), f"{nm} y-string differs from the reference run"
+        assert enc["strings"][1][0] == g[f"{tag}/enc/{nm}_z"].tobytes(), f"{nm} z-string differs from the reference run"
+        assert tuple(enc["shape"]) == tuple(g[f"{tag}/enc/{nm}_shape"])
+    dec = oracle_w0.decompress(ref, mv, res, sm, feat)
+    for j, name in enumerate(["feature", "recon", "warped", "predict"]):
+        _check(g, f"{tag}/dec/{name}", dec[j])
+
+
+def test_state_dict_contract(w0_state_dict, golden64):
+    """Checkpoint compatibility: the product exposes exactly the reference's non-entropy keys and shapes."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    want = {}
+    for line in open(os.path.join(here, "golden", "state_dict_keys.txt")):
+        k, shp = line.split(" ", 1)
+        want[k] = tuple(eval(shp))
+    have = {k: tuple(v.shape) for k, v in w0_state_dict.items() if "entropy_bottleneck" not in k and "gaussian_conditional" not in k}
+    assert have == want
+    assert int(golden64["meta/n_keys_non_entropy"][0]) == 942  # SURVEY.md section 5 (checkpoint row)
+    assert int(golden64["meta/n_params"][0]) == 20684033       # SURVEY.md section 2.2 (video_model.py:196 would print it)
+
+
+def test_real_bpp_close_to_estimate(oracle_w0):
+    """SURVEY 8c property: real bitstream size tracks the likelihood estimate (same order; escape coding
+    and table quantisation make it differ)."""
+    ref, cur, sm, feat = _inputs(64, False)
+    out = oracle_w0.forward(ref, cur, sm, feat)
+    mv, res = oracle_w0.compress(ref, cur, sm, feat)
+    real = (strings_nbytes(mv) + strings_nbytes(res)) * 8 / (64 * 64)
+    est = float(out[7])
+    assert 0.5 * est < real < 1.5 * est
