@@ -1,0 +1,224 @@
+// conv3x3_ws.hip -- bf16 3x3 stride-1 convolution with <= 64 input channels at large resolution: the shape family
+// that carries ~2/3 of a P-frame's MACs (ResBlock1 / ResBottleneck conv2 /
+// in_conv / weight heads of modules.py:177,200-204,307-311,322-340,382-418).
+//
+// Structure -- chosen for compiler-scheduled HIP on CDNA4, where latency is hidden by having
+// two waves per SIMD rather than by hand-placed instruction streams:
+//   * PERSISTENT workgroups, one per CU, 8 waves (2 per SIMD), walking 16x32-pixel tiles: no block launch tail;
+//   * WEIGHT-STATIONARY: all taps x input chunks x output channels of the conv (<= 92 KiB with the 80-B row pitch)
+//     are staged into LDS ONCE per workgroup and stay there; per tile only the input halo patch moves
+//     (the generic kernel re-stages the weights for every 8x32 tile: 63 % of its L2->LDS traffic);
+//   * the patch of the NEXT (tile, channel chunk) is prefetched into registers with unconditional, clamped,
+//     straight-line loads before the current chunk's MFMA phase and written to LDS after it (async-stage split):
+//     HBM/L2 latency rides under 36 MFMAs per wave; zero padding and the fused ResBlock pre-activation are
+//     applied on the way into LDS;
+//   * wave w owns tile rows 2w, 2w+1 (two MFMA M-tiles) and all NT*32 output channels; LDS rows are 64 B + 16 B pad
+//     (conflict-free ds_read_b128); the A/B byte->k assignment is the generic kernel's;
+//   * epilogue = the shared fused pass through wave-private LDS slabs that alias the (then idle) patch buffer.
+#include "conv_common.h"
+
+using namespace dsvc_conv;
+
+namespace {
+
+constexpr int WS_TH = 16, WS_PH = 18, WS_PW = 34, WS_NPATCH = WS_PH * WS_PW;   // 612 patch pixels
+constexpr int WS_PFV = (WS_NPATCH * 4 + 511) / 512;                            // 5 prefetch vectors per thread
+
+template <int NT, bool FAST>
+__global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(const ConvParams p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTN = NT * 32, KCE = 32, EPV = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nchunks = p.nchunks;
+    char* lds_w = smem;                                              // [chunk][tap][NTN] rows of 80 B
+    char* lds_a = smem + (size_t)nchunks * 9 * NTN * ROWB;           // 612 rows of 80 B; epilogue slabs alias it
+    float* slab = (float*)lds_a + wave * (32 * 36);
+    const EpiRsrc R = make_epi_rsrc(p);
+
+    // ---- stage every weight row once (batched 16-B copies) ----
+    {
+        const int nrows = nchunks * 9 * NTN;                         // global rows are [chunk][tap][Np] x 64 B, Np == NTN here
+        const int q = tid & 3;
+        for (int base = tid >> 2; base < nrows; base += 128 * 6) {
+            uint4 v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int row = base + 128 * j;
+                v[j] = make_uint4(0, 0, 0, 0);
+                if (row < nrows) v[j] = *(const uint4*)((const char*)p.w + (size_t)row * 64 + q * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (base + 128 * j < nrows) *(uint4*)(lds_w + (base + 128 * j) * ROWB + q * 16) = v[j];
+        }
+    }
+
+    const int H = p.H, W = p.W, tiles_x = p.tiles_x, tiles_y = p.tiles_y, pre_act = p.pre_act;
+    const float pre_sl = pre_act == DSVC_ACT_RELU ? 0.f : p.slope;
+    auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
+        const int tx = tile % tiles_x;
+        const int rest = tile / tiles_x;
+        const int ty = rest % tiles_y;
+        b = rest / tiles_y;
+        oy0 = ty * WS_TH; ox0 = tx * 32;
+    };
+    // patch vector v = tid + 512*j  ->  pixel v>>2 (row-major in the 18x34 patch), 16-B quarter v&3
+    const int q = tid & 3;
+    int ppy[WS_PFV], ppx[WS_PFV];
+#pragma unroll
+    for (int j = 0; j < WS_PFV; ++j) {
+        const int pix = (tid >> 2) + 128 * j;
+        ppy[j] = pix / WS_PW; ppx[j] = pix - ppy[j] * WS_PW;
+    }
+    auto seg_of = [&](int ch) {
+        int s = 0;
+        if (p.nseg > 1 && ch >= p.seg[1].chunk0) s = 1;
+        if (p.nseg > 2 && ch >= p.seg[2].chunk0) s = 2;
+        return s;
+    };
+    auto load_chunk = [&](int tile, int ch, uint4 (&pf)[WS_PFV]) {
+        int b, oy0, ox0;
+        tile_origin(tile, b, oy0, ox0);
+        const ConvSeg& sg = p.seg[seg_of(ch)];
+        const int c0 = (ch - sg.chunk0) * KCE;
+#pragma unroll
+        for (int j = 0; j < WS_PFV; ++j) {
+            const int iy = oy0 - 1 + ppy[j], ix = ox0 - 1 + ppx[j];
+            if constexpr (FAST) {   // bounds-checked buffer load: out-of-image pixels read as zeros, code stays straight-line
+                const bool inb = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                pf[j] = buf_load16(make_rsrc(sg.ptr, sg.bytes), inb ? ((((unsigned)b * H + iy) * W + ix) * sg.ld + c0) * 2 + q * 16 : OOB);
+            } else {
+                pf[j] = make_uint4(0, 0, 0, 0);
+                if ((tid >> 2) + 128 * j < WS_NPATCH && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    float vals[EPV];
+                    load_vec<EPV>(sg, (((int64_t)b * H + iy) * W + ix) * sg.ld, c0 + q * EPV, vals);
+                    pf[j] = pack_vec<__bf16, EPV>(vals);
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](uint4 (&pf)[WS_PFV]) {
+#pragma unroll
+        for (int j = 0; j < WS_PFV; ++j) {
+            const int pix = (tid >> 2) + 128 * j;
+            if (pix >= WS_NPATCH) continue;
+            uint4 val = pf[j];
+            if (pre_act != DSVC_ACT_NONE) {   // ResBlock1's leading ReLU / LeakyReLU on the packed bf16 pairs
+                unsigned u[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
+                    u[k] = (unsigned)f32_to_bf16_bits(fmaxf(lo, lo * pre_sl)) | ((unsigned)f32_to_bf16_bits(fmaxf(hi, hi * pre_sl)) << 16);
+                }
+                val = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+            *(uint4*)(lds_a + pix * ROWB + q * 16) = val;
+        }
+    };
+
+    int tile = blockIdx.x;
+    uint4 pf[WS_PFV];
+    load_chunk(min(tile, ntiles - 1), 0, pf);
+    store_chunk(pf);
+    __syncthreads();
+
+    int a_off[2], b_off[NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) a_off[m] = ((wave * 2 + m) * WS_PW + r) * ROWB + h * 32;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b_off[n] = (n * 32 + r) * ROWB + h * 32;
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            // what the patch buffer must hold next: the following chunk of this tile, or chunk 0 of the next tile
+            const bool last = ch + 1 == nchunks;
+            const int ntile = last ? min(tile + (int)gridDim.x, ntiles - 1) : tile;
+            const int nch = last ? 0 : ch + 1;
+            load_chunk(ntile, nch, pf);                          // in flight during this chunk's 36 MFMAs / wave
+            __builtin_amdgcn_sched_barrier(0);                   // hipcc otherwise sinks these loads below the MFMA phase
+
+            const char* wt = lds_w + (size_t)ch * 9 * NTN * ROWB;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int tap_off = ((t / 3) * WS_PW + (t % 3)) * ROWB;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint4 af[2], bf[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bf[n] = *(const uint4*)(wt + t * NTN * ROWB + b_off[n] + ks * 16);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) af[m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[m]),
+                                                                                 __builtin_bit_cast(bf16x8, bf[n]), acc[m][n], 0, 0, 0);
+                }
+            }
+
+            __syncthreads();                                     // every wave is done reading this chunk's patch
+            if (last) {                                          // epilogue through slabs that alias the patch buffer
+                int b, oy0, ox0;
+                tile_origin(tile, b, oy0, ox0);
+                // passes written out with static accumulator indices (a rolled (m,n) loop would push acc[][] to scratch)
+#define WS_PASS(M, N)                                                                                              \
+    if constexpr (N < NT) {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) slab[((i & 3) + 8 * (i >> 2) + 4 * h) * 36 + r] = acc[M][N][i]; \
+        __builtin_amdgcn_wave_barrier();                                                                           \
+        run_epilogue<8, 36, 32>(p, R, slab, lane, b, oy0 + wave * 2 + M, ox0, N * 32, 32);                         \
+        __builtin_amdgcn_wave_barrier();                                                                           \
+    }
+                WS_PASS(0, 0) WS_PASS(0, 1) WS_PASS(1, 0) WS_PASS(1, 1)
+#undef WS_PASS
+                __syncthreads();                                 // slabs are dead before the patch buffer is refilled
+            }
+            store_chunk(pf);
+            __syncthreads();
+        }
+    }
+}
+
+template <int NT, bool FAST>
+int launch_ws(hipStream_t st, const ConvParams& p, int ntiles) {
+    const size_t lds = (size_t)p.nchunks * 9 * NT * 32 * ROWB + (size_t)WS_NPATCH * ROWB;
+    static bool attr_set = false;
+    auto kern = conv3x3_ws_kernel<NT, FAST>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
+        attr_set = true;
+    }
+    const int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, ntiles);
+    DSVC_CHECK_LAUNCH("conv3x3_ws_kernel");
+    return DSVC_OK;
+}
+
+}  // namespace
+
+// returns 1 when the shape is not covered (caller falls back to the generic kernel), else DSVC_OK / error
+int dsvc_conv3x3_ws_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
+    if (d->compute != DSVC_BF16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
+    if (p_in.nchunks > 2 || d->Cout > 64) return 1;
+    ConvParams p = p_in;
+    p.tiles_x = (p.Wo + 31) / 32;
+    p.tiles_y = (p.Ho + WS_TH - 1) / WS_TH;
+    const int ntiles = p.B * p.tiles_x * p.tiles_y;
+    if (ntiles < 512) return 1;            // small images: the generic kernel's finer tiling fills the chip better
+    bool fast = true;
+    for (int s = 0; s < p.nseg; ++s) fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == DSVC_BF16 && (p.seg[s].C % 32) == 0;
+    const int NT = d->Cout > 32 ? 2 : 1;
+    if (fast) return NT == 2 ? launch_ws<2, true>(st, p, ntiles) : launch_ws<1, true>(st, p, ntiles);
+    return NT == 2 ? launch_ws<2, false>(st, p, ntiles) : launch_ws<1, false>(st, p, ntiles);
+}

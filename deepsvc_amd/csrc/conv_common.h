@@ -1,0 +1,295 @@
+// conv_common.h -- parameter block and fused epilogue shared by the conv kernels (conv_mfma.hip, conv3x3_rs.hip).
+#pragma once
+#include "common.h"
+
+namespace dsvc_conv {
+
+constexpr int ROWB = 80;   // LDS row pitch in bytes
+constexpr int TW = 32;     // tile width in output pixels == MFMA M
+
+struct ConvSeg {
+    const void* ptr;
+    int C, ld, dtype, vec_ok, chunk0;
+    unsigned bytes;      // extent from ptr to the end of the last pixel's slice (buffer-resource num_records)
+};
+
+struct ConvParams {
+    ConvSeg seg[3];
+    int nseg, nchunks;
+    int B, H, W, Ho, Wo;
+    int kh, kw, stride, pad;
+    int Cout, Np;
+    const void* w;
+    const float* bias;
+    int pre_act, act;
+    float slope;
+    const void* res1; int res1_ld, res1_dtype, res1_vec; const float* res1_scale;
+    const void* res2; int res2_ld, res2_dtype, res2_vec;
+    void* out; int out_ld, out_dtype, out_vec, shuffle;
+    int tiles_x, tiles_y, tapg;
+    unsigned out_bytes, res1_bytes, res2_bytes;   // extents for the buffer resources of the vector epilogue
+    int epi_vec;                                   // 1: epilogue may use 4-channel vector buffer ops everywhere
+};
+
+// ---- raw buffer resources: hardware bounds checking instead of branches ------------------------------------------
+// A lane that must not touch memory -- masked pixel, absent operand, or the view of the other element type -- gets
+// the out-of-range offset OOB (loads return 0, stores are dropped).  The code stays straight-line,
+// so hipcc's waitcnt insertion emits counted waits at first use instead of vmcnt(0) at every control-flow merge.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+constexpr unsigned OOB = 0x80000000u;   // beyond any extent (< 2 GiB enforced on the host); offset + 16 cannot wrap
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(rsrc_t r, unsigned off) {
+    const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+struct EpiRsrc {      // one descriptor per operand (an absent residual borrows the output's; its offsets are all OOB)
+    rsrc_t out, r1, r2;
+    bool out_f32, r1_f32, r1_bf16, r2_f32, r2_bf16;
+};
+__device__ __forceinline__ EpiRsrc make_epi_rsrc(const ConvParams& p) {
+    EpiRsrc R;
+    R.out = make_rsrc(p.out, p.out_bytes);
+    R.r1 = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? p.res1_bytes : p.out_bytes);
+    R.r2 = make_rsrc(p.res2 ? p.res2 : p.out, p.res2 ? p.res2_bytes : p.out_bytes);
+    R.out_f32 = p.out_dtype == DSVC_F32;
+    R.r1_f32 = p.res1 && p.res1_dtype == DSVC_F32; R.r1_bf16 = p.res1 && p.res1_dtype == DSVC_BF16;
+    R.r2_f32 = p.res2 && p.res2_dtype == DSVC_F32; R.r2_bf16 = p.res2 && p.res2_dtype == DSVC_BF16;
+    return R;
+}
+
+
+// ---- fused epilogue pass over one wave-private LDS slab, specialised per activation -------------------------
+// Lane -> (channel group g = lane % GPP fixed for the whole pass, pixel lanes step 64/GPP): bias/gate are loaded once,
+// residuals and outputs move as 16-byte (fp32) / 8-byte (bf16) vectors along the channel axis.
+template <int ACT>
+__device__ __forceinline__ float act_t(float v, float slope) {
+    if constexpr (ACT == DSVC_ACT_RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == DSVC_ACT_LRELU) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == DSVC_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    else if constexpr (ACT == DSVC_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    else if constexpr (ACT == DSVC_ACT_HALF_TANH) return 0.5f * tanhf(v);
+    else return v;
+}
+
+__device__ __forceinline__ void load4(const void* base, int dtype, int vec, int64_t off, int nv, float (&o)[4]) {
+    if (vec && nv == 4) {
+        if (dtype == DSVC_F32) {
+            const float4 t = *(const float4*)((const float*)base + off);
+            o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+        } else {
+            const uint2 t = *(const uint2*)((const unsigned short*)base + off);
+            o[0] = __builtin_bit_cast(float, t.x << 16); o[1] = __builtin_bit_cast(float, t.x & 0xFFFF0000u);
+            o[2] = __builtin_bit_cast(float, t.y << 16); o[3] = __builtin_bit_cast(float, t.y & 0xFFFF0000u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = j < nv ? load_elem(base, dtype, off + j) : 0.f;
+    }
+}
+
+template <int ACT, int GPP, int EPLD>
+__device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* slab, int lane, int npl, int b, int oy_base,
+                                              int ox0, int co0, int cpass) {
+    const int g = lane % GPP;
+    const int co = co0 + g * 4;
+    if (g * 4 >= cpass || co >= p.Cout) return;
+    const int nv = min(4, p.Cout - co);
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, gate[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (p.bias && j < nv) bias[j] = p.bias[co + j];
+        if (p.res1_scale && j < nv) gate[j] = p.res1_scale[(int64_t)b * p.Cout + co + j];
+    }
+    for (int pl = lane / GPP; pl < npl; pl += 64 / GPP) {
+        const int oy = oy_base + (pl >> 5), ox = ox0 + (pl & 31);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const float4 a4 = *(const float4*)(slab + pl * EPLD + g * 4);
+        float v[4] = {act_t<ACT>(a4.x + bias[0], p.slope), act_t<ACT>(a4.y + bias[1], p.slope),
+                      act_t<ACT>(a4.z + bias[2], p.slope), act_t<ACT>(a4.w + bias[3], p.slope)};
+        const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+        if (p.shuffle == 1) {
+            if (p.res1) {
+                float r[4];
+                load4(p.res1, p.res1_dtype, p.res1_vec, opix * p.res1_ld + co, nv, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += gate[j] * r[j];
+            }
+            if (p.res2) {
+                float r[4];
+                load4(p.res2, p.res2_dtype, p.res2_vec, opix * p.res2_ld + co, nv, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += r[j];
+            }
+            const int64_t oo = opix * p.out_ld + co;
+            if (p.out_vec && nv == 4) {
+                if (p.out_dtype == DSVC_F32) {
+                    *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 u;
+                    u.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+                    u.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                    *(uint2*)((unsigned short*)p.out + oo) = u;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nv) store_elem(p.out, p.out_dtype, oo + j, v[j]);
+            }
+        } else {  // PixelShuffle(2): conv channel co+j = cq*4 + dy*2 + dx  (co % 4 == 0, Cout % 4 == 0)
+            const int cq = co >> 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t spix = ((int64_t)b * (2 * p.Ho) + 2 * oy + (j >> 1)) * (2 * p.Wo) + 2 * ox + (j & 1);
+                float o = v[j];
+                if (p.res1) o += load_elem(p.res1, p.res1_dtype, spix * p.res1_ld + cq);
+                store_elem(p.out, p.out_dtype, spix * p.out_ld + cq, o);
+            }
+        }
+    }
+}
+
+
+// ---- straight-line vector epilogue: NPL pixels of a wave-private slab, 4 channels per lane -------------------------
+template <int ACT, bool HAS_RES, int GPP, int EPLD, int NPL>
+__device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc& R, const float* slab, int lane, int b,
+                                             int oy_base, int ox0, int co0, int cpass) {
+    const int g = lane % GPP;
+    const int co = co0 + g * 4;
+    const bool lane_ok = g * 4 < cpass && co < p.Cout;     // Cout % 4 == 0 on this path
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, gate[4] = {1.f, 1.f, 1.f, 1.f};
+    if (lane_ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p.bias) bias[j] = p.bias[co + j];
+            if (p.res1_scale) gate[j] = p.res1_scale[(int64_t)b * p.Cout + co + j];
+        }
+    }
+    constexpr int STEP = 64 / GPP;
+#pragma unroll 4
+    for (int it = 0; it < NPL / STEP; ++it) {   // 4 iterations in flight: enough to overlap the residual loads
+        const int pl = lane / GPP + it * STEP;
+        const int oy = oy_base + (pl >> 5), ox = ox0 + (pl & 31);
+        const bool ok = lane_ok && oy < p.Ho && ox < p.Wo;
+        const unsigned opix = ((unsigned)b * p.Ho + oy) * p.Wo + ox;
+        const float4 a4 = *(const float4*)(slab + pl * EPLD + g * 4);
+        float v[4] = {act_t<ACT>(a4.x + bias[0], p.slope), act_t<ACT>(a4.y + bias[1], p.slope),
+                      act_t<ACT>(a4.z + bias[2], p.slope), act_t<ACT>(a4.w + bias[3], p.slope)};
+        if constexpr (HAS_RES) {
+            const unsigned e1 = opix * p.res1_ld + co, e2 = opix * p.res2_ld + co;
+            const v4u_t f1 = __builtin_amdgcn_raw_buffer_load_b128(R.r1, (ok && R.r1_f32) ? e1 * 4 : OOB, 0, 0);
+            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_bf16) ? e1 * 2 : OOB, 0, 0);
+            const v4u_t f2 = __builtin_amdgcn_raw_buffer_load_b128(R.r2, (ok && R.r2_f32) ? e2 * 4 : OOB, 0, 0);
+            const v2u_t h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_bf16) ? e2 * 2 : OOB, 0, 0);
+            // NB: lanes are copied to scalars first -- __builtin_bit_cast applied directly to an ext-vector element
+            // (f1.y) is compiled as a cast of element 0 by hipcc 7.2.
+            const unsigned a1[4] = {f1.x, f1.y, f1.z, f1.w}, a2[4] = {f2.x, f2.y, f2.z, f2.w};
+            const unsigned b1[4] = {h1.x << 16, h1.x & 0xFFFF0000u, h1.y << 16, h1.y & 0xFFFF0000u};
+            const unsigned b2[4] = {h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+            float r1[4], r2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r1[j] = __builtin_bit_cast(float, a1[j]) + __builtin_bit_cast(float, b1[j]);
+                r2[j] = __builtin_bit_cast(float, a2[j]) + __builtin_bit_cast(float, b2[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += gate[j] * r1[j] + r2[j];
+        }
+        const unsigned eo = opix * p.out_ld + co;
+        v4u_t of;
+        of.x = __builtin_bit_cast(unsigned, v[0]); of.y = __builtin_bit_cast(unsigned, v[1]);
+        of.z = __builtin_bit_cast(unsigned, v[2]); of.w = __builtin_bit_cast(unsigned, v[3]);
+        v2u_t ob;
+        ob.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        ob.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        __builtin_amdgcn_raw_buffer_store_b128(of, R.out, (ok && R.out_f32) ? eo * 4 : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(ob, R.out, (ok && !R.out_f32) ? eo * 2 : OOB, 0, 0);
+    }
+}
+
+// one epilogue pass: vector path (straight-line, buffer ops) when the host proved alignment, else the general path
+template <int GPP, int EPLD, int NPL>
+__device__ __forceinline__ void run_epilogue(const ConvParams& p, const EpiRsrc& R, const float* slab, int lane, int b,
+                                             int oy_base, int ox0, int co0, int cpass) {
+#define DSVC_EPI_CASE(A)                                                                                            \
+    case A:                                                                                                         \
+        if (!p.epi_vec) epilogue_pass<A, GPP, EPLD>(p, slab, lane, NPL, b, oy_base, ox0, co0, cpass);               \
+        else if (p.res1 || p.res2) epilogue_vec<A, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
+        else epilogue_vec<A, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);                 \
+        break;
+    switch (p.act) {
+        DSVC_EPI_CASE(DSVC_ACT_RELU)
+        DSVC_EPI_CASE(DSVC_ACT_LRELU)
+        DSVC_EPI_CASE(DSVC_ACT_GELU)
+        DSVC_EPI_CASE(DSVC_ACT_SIGMOID)
+        DSVC_EPI_CASE(DSVC_ACT_HALF_TANH)
+        default:
+            if (!p.epi_vec) epilogue_pass<DSVC_ACT_NONE, GPP, EPLD>(p, slab, lane, NPL, b, oy_base, ox0, co0, cpass);
+            else if (p.res1 || p.res2) epilogue_vec<DSVC_ACT_NONE, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+            else epilogue_vec<DSVC_ACT_NONE, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+            break;
+    }
+#undef DSVC_EPI_CASE
+}
+
+template <typename CT> struct CTraits;
+template <> struct CTraits<float> { static constexpr int KCE = 16, EPV = 4; };
+template <> struct CTraits<__bf16> { static constexpr int KCE = 32, EPV = 8; };
+
+template <int EPV>
+__device__ __forceinline__ void load_vec(const ConvSeg& sg, int64_t off, int c, float (&v)[EPV]) {
+    const int nvalid = sg.C - c;
+    if (nvalid >= EPV && sg.vec_ok) {
+        if (sg.dtype == DSVC_F32) {
+            const float4* p = (const float4*)((const float*)sg.ptr + off + c);
+#pragma unroll
+            for (int j = 0; j < EPV / 4; ++j) {
+                float4 t = p[j];
+                v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+            }
+        } else {
+            const unsigned short* p = (const unsigned short*)sg.ptr + off + c;
+            if (EPV == 8) {
+                uint4 t = *(const uint4*)p;
+                unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[2 * j] = __builtin_bit_cast(float, u[j] << 16);
+                    v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u);
+                }
+            } else {
+                uint2 t = *(const uint2*)p;
+                unsigned u[2] = {t.x, t.y};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    v[2 * j] = __builtin_bit_cast(float, u[j] << 16);
+                    v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) v[j] = (j < nvalid) ? load_elem(sg.ptr, sg.dtype, off + c + j) : 0.f;
+    }
+}
+
+template <typename CT, int EPV>
+__device__ __forceinline__ uint4 pack_vec(const float (&v)[EPV]) {
+    if constexpr (sizeof(CT) == 4) {
+        return make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                          __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+    } else {
+        unsigned u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            u[j] = (unsigned)f32_to_bf16_bits(v[2 * j]) | ((unsigned)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+        return make_uint4(u[0], u[1], u[2], u[3]);
+    }
+}
+
+}  // namespace dsvc_conv

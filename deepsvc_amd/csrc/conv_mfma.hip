@@ -20,90 +20,15 @@
 //   bf16 compute: v_mfma_f32_32x32x16_bf16, 1 MFMA per 16-B fragment pair, fp32 accumulate.
 //   Epilogue (fused): + bias, activation, + residual (optionally gated per channel: SELayer),
 //   + second residual, optional PixelShuffle(2) scatter, cast to the output storage type.
-#include "common.h"
+#include <cstdlib>
+#include "conv_common.h"
+
+int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 namespace {
+using namespace dsvc_conv;
 
-constexpr int ROWB = 80;   // LDS row pitch in bytes
-constexpr int TW = 32;     // tile width in output pixels == MFMA M
-
-struct ConvSeg {
-    const void* ptr;
-    int C, ld, dtype, vec_ok, chunk0;
-};
-
-struct ConvParams {
-    ConvSeg seg[3];
-    int nseg, nchunks;
-    int B, H, W, Ho, Wo;
-    int kh, kw, stride, pad;
-    int Cout, Np;
-    const void* w;
-    const float* bias;
-    int pre_act, act;
-    float slope;
-    const void* res1; int res1_ld, res1_dtype; const float* res1_scale;
-    const void* res2; int res2_ld, res2_dtype;
-    void* out; int out_ld, out_dtype, shuffle;
-    int tiles_x, tiles_y, tapg;
-};
-
-template <typename CT> struct CTraits;
-template <> struct CTraits<float> { static constexpr int KCE = 16, EPV = 4; };
-template <> struct CTraits<__bf16> { static constexpr int KCE = 32, EPV = 8; };
-
-template <int EPV>
-__device__ __forceinline__ void load_vec(const ConvSeg& sg, int64_t off, int c, float (&v)[EPV]) {
-    const int nvalid = sg.C - c;
-    if (nvalid >= EPV && sg.vec_ok) {
-        if (sg.dtype == DSVC_F32) {
-            const float4* p = (const float4*)((const float*)sg.ptr + off + c);
-#pragma unroll
-            for (int j = 0; j < EPV / 4; ++j) {
-                float4 t = p[j];
-                v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
-            }
-        } else {
-            const unsigned short* p = (const unsigned short*)sg.ptr + off + c;
-            if (EPV == 8) {
-                uint4 t = *(const uint4*)p;
-                unsigned u[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[2 * j] = __builtin_bit_cast(float, u[j] << 16);
-                    v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u);
-                }
-            } else {
-                uint2 t = *(const uint2*)p;
-                unsigned u[2] = {t.x, t.y};
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    v[2 * j] = __builtin_bit_cast(float, u[j] << 16);
-                    v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < EPV; ++j) v[j] = (j < nvalid) ? load_elem(sg.ptr, sg.dtype, off + c + j) : 0.f;
-    }
-}
-
-template <typename CT, int EPV>
-__device__ __forceinline__ uint4 pack_vec(const float (&v)[EPV]) {
-    if constexpr (sizeof(CT) == 4) {
-        return make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
-                          __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
-    } else {
-        unsigned u[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            u[j] = (unsigned)f32_to_bf16_bits(v[2 * j]) | ((unsigned)f32_to_bf16_bits(v[2 * j + 1]) << 16);
-        return make_uint4(u[0], u[1], u[2], u[3]);
-    }
-}
-
-template <typename CT, int MT, int NT>
+template <typename CT, int MT, int NT, bool FAST>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KCE = CTraits<CT>::KCE, EPV = CTraits<CT>::EPV;
@@ -135,7 +60,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-    const int frag_off = h * 32;  // byte offset of this lane's K half inside a 64-B chunk row
+    // per-thread staging walk: vector q of patch pixel (py,px), advancing 64 pixels per step without divisions
+    const int q = tid & 3;
+    const int pix0 = tid >> 2;
+    const int py0 = pix0 / PW, px0 = pix0 - py0 * PW;
+    const int dpy = 64 / PW, dpx = 64 - dpy * PW;
+    // fragment read offsets: lane (r,h) takes bytes [32h + 16ks, +16) of row r
+    int a_off[MT], b_off[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_off[m] = (((wave * MT + m) * p.stride) * PW + r * p.stride) * ROWB + h * 32;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b_off[n] = (n * 32 + r) * ROWB + h * 32;
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         int s = 0;
@@ -146,54 +81,102 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
 
         __syncthreads();  // all waves done with the previous chunk's LDS contents
         // ---- stage the input halo patch of this channel chunk ----
-        for (int v = tid; v < npatch * 4; v += 256) {
-            const int pix = v >> 2, q = v & 3;
-            const int py = pix / PW, px = pix - py * PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            float vals[EPV];
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                const int64_t off = (((int64_t)b * p.H + iy) * p.W + ix) * sg.ld;
-                load_vec<EPV>(sg, off, c0 + q * EPV, vals);
-                if (p.pre_act != DSVC_ACT_NONE) {
+        // Loads of a batch are all issued before the first LDS store so their L2/HBM latencies overlap.
+        if constexpr (FAST) {  // storage type == compute type, 16-B aligned, whole chunks
+            constexpr int PB = 6;
+            const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);      // out-of-image pixels read as zeros (bounds-checked loads)
+            const unsigned pitch = (unsigned)sg.ld * sizeof(CT);
+            const unsigned img = (unsigned)b * p.H * p.W * pitch + c0 * (unsigned)sizeof(CT) + q * 16;
+            int py = py0, px = px0;
+            for (int base = pix0; base < npatch; base += 64 * PB) {
+                uint4 v[PB];
 #pragma unroll
-                    for (int j = 0; j < EPV; ++j) vals[j] = apply_act(vals[j], p.pre_act, p.slope);
+                for (int j = 0; j < PB; ++j) {
+                    const int iy = iy0 + py, ix = ix0 + px;
+                    const bool inb = base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    v[j] = buf_load16(rs, inb ? img + ((unsigned)iy * p.W + ix) * pitch : OOB);
+                    px += dpx; py += dpy;
+                    if (px >= PW) { px -= PW; ++py; }
                 }
-            } else {
+                if (p.pre_act != DSVC_ACT_NONE) {  // ResBlock1's leading ReLU / LeakyReLU, applied on the packed vector
+                    const float sl = p.pre_act == DSVC_ACT_RELU ? 0.f : p.slope;
 #pragma unroll
-                for (int j = 0; j < EPV; ++j) vals[j] = 0.f;
+                    for (int j = 0; j < PB; ++j) {
+                        unsigned u[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if constexpr (sizeof(CT) == 4) {
+                                const float f = __builtin_bit_cast(float, u[k]);
+                                u[k] = __builtin_bit_cast(unsigned, fmaxf(f, f * sl));
+                            } else {
+                                const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
+                                u[k] = (unsigned)f32_to_bf16_bits(fmaxf(lo, lo * sl)) | ((unsigned)f32_to_bf16_bits(fmaxf(hi, hi * sl)) << 16);
+                            }
+                        }
+                        v[j] = make_uint4(u[0], u[1], u[2], u[3]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PB; ++j)
+                    if (base + 64 * j < npatch) *(uint4*)(lds_a + (base + 64 * j) * ROWB + q * 16) = v[j];
             }
-            *(uint4*)(lds_a + pix * ROWB + q * 16) = pack_vec<CT, EPV>(vals);
+        } else {
+            int py = py0, px = px0;
+            for (int pix = pix0; pix < npatch; pix += 64) {
+                const int iy = iy0 + py, ix = ix0 + px;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    float vals[EPV];
+                    load_vec<EPV>(sg, (((int64_t)b * p.H + iy) * p.W + ix) * sg.ld, c0 + q * EPV, vals);
+                    if (p.pre_act != DSVC_ACT_NONE) {
+                        const float sl = p.pre_act == DSVC_ACT_RELU ? 0.f : p.slope;
+#pragma unroll
+                        for (int j = 0; j < EPV; ++j) vals[j] = fmaxf(vals[j], vals[j] * sl);
+                    }
+                    val = pack_vec<CT, EPV>(vals);
+                }
+                *(uint4*)(lds_a + pix * ROWB + q * 16) = val;
+                px += dpx; py += dpy;
+                if (px >= PW) { px -= PW; ++py; }
+            }
         }
 
+        int ky = 0, kx = 0;
         for (int tg0 = 0; tg0 < ntaps; tg0 += p.tapg) {
             const int tcur = min(p.tapg, ntaps - tg0);
             if (tg0 > 0) __syncthreads();
-            // ---- stage the weights of taps [tg0, tg0+tcur) for this chunk and N group ----
-            const char* wbase = (const char*)p.w + ((size_t)ch * ntaps + tg0) * p.Np * 64;
-            for (int v = tid; v < tcur * NTN * 4; v += 256) {
-                const int row = v >> 2, q = v & 3;
-                const int t = row / NTN, n = row - t * NTN;
-                const int ngl = ng * NTN + n;
-                uint4 val = make_uint4(0, 0, 0, 0);
-                if (ngl < p.Np) val = *(const uint4*)(wbase + ((size_t)t * p.Np + ngl) * 64 + q * 16);
-                *(uint4*)(lds_w + row * ROWB + q * 16) = val;
+            // ---- stage the weights of taps [tg0, tg0+tcur) for this chunk and N group (batched loads) ----
+            {
+                constexpr int WB = 9;
+                const char* wbase = (const char*)p.w + (((size_t)ch * ntaps + tg0) * p.Np + (size_t)ng * NTN) * 64 + q * 16;
+                const bool wfull = (ng + 1) * NTN <= p.Np;
+                const int nrows = tcur * NTN;
+                for (int base = tid >> 2; base < nrows; base += 64 * WB) {
+                    uint4 v[WB];
+#pragma unroll
+                    for (int j = 0; j < WB; ++j) {
+                        const int row = base + 64 * j;
+                        const int t = row / NTN, n = row - t * NTN;
+                        v[j] = make_uint4(0, 0, 0, 0);
+                        if (row < nrows && (wfull || ng * NTN + n < p.Np)) v[j] = *(const uint4*)(wbase + ((size_t)t * p.Np + n) * 64);
+                    }
+#pragma unroll
+                    for (int j = 0; j < WB; ++j)
+                        if (base + 64 * j < nrows) *(uint4*)(lds_w + (base + 64 * j) * ROWB + q * 16) = v[j];
+                }
             }
             __syncthreads();
 
             for (int t = 0; t < tcur; ++t) {
-                const int tap = tg0 + t;
-                const int ky = tap / p.kw, kx = tap - ky * p.kw;
+                const int tap_off = (ky * PW + kx) * ROWB;
+                const char* wt = lds_w + t * NTN * ROWB;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     uint4 af[MT], bf[NT];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        bf[n] = *(const uint4*)(lds_w + (t * NTN + n * 32 + r) * ROWB + frag_off + ks * 16);
+                    for (int n = 0; n < NT; ++n) bf[n] = *(const uint4*)(wt + b_off[n] + ks * 16);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int prow = (wave * MT + m) * p.stride + ky;
-                        af[m] = *(const uint4*)(lds_a + (prow * PW + r * p.stride + kx) * ROWB + frag_off + ks * 16);
-                    }
+                    for (int m = 0; m < MT; ++m) af[m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -210,18 +193,19 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                             }
                         }
                 }
+                if (++kx == p.kw) { kx = 0; ++ky; }
             }
         }
     }
 
     // ---- epilogue ----
     // MFMA C/D layout: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel).
-    // Accumulators go through a wave-private LDS slab [pixel][channel] (<= 2 N-tiles per pass) so the
-    // fused bias/activation/residual/store code exists once, in a rolled loop, and global traffic is
-    // 16-byte vectors along the channel axis (NHWC contiguous).
+    // Accumulators go through a wave-private LDS slab [pixel][channel] (<= 2 N-tiles per pass) so the fused
+    // bias/activation/residual/store code is a short rolled loop moving 16-byte vectors along the NHWC channel axis.
     constexpr int EPN = NT >= 2 ? 2 : 1;
     constexpr int EPC = EPN * 32, EPLD = EPC + 4, GPP = EPC / 4;
     float* slab = (float*)smem + (size_t)wave * (MT * 32 * EPLD);
+    const EpiRsrc R = make_epi_rsrc(p);
 #pragma unroll
     for (int n0 = 0; n0 < NT; n0 += EPN) {
         __syncthreads();
@@ -237,69 +221,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         }
         __syncthreads();
         const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
-        for (int it = lane; it < MT * 32 * GPP; it += 64) {
-            const int pl = it / GPP, g = it - pl * GPP;
-            const int m = pl >> 5, row = pl & 31;
-            const int oy = oy0 + wave * MT + m, ox = ox0 + row;
-            const int co = ng * NTN + n0 * 32 + g * 4;
-            if (g * 4 >= cpass || oy >= p.Ho || ox >= p.Wo || co >= p.Cout) continue;
-            const int nv = min(4, p.Cout - co);
-            const float4 a4 = *(const float4*)(slab + pl * EPLD + g * 4);
-            float v[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float bias = (p.bias && j < nv) ? p.bias[co + j] : 0.f;
-                v[j] = apply_act(v[j] + bias, p.act, p.slope);
-            }
-            const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
-            if (p.shuffle == 1) {
-                if (p.res1) {
-                    const int64_t ro = opix * p.res1_ld + co;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < nv) {
-                            const float gate = p.res1_scale ? p.res1_scale[(int64_t)b * p.Cout + co + j] : 1.f;
-                            v[j] += gate * load_elem(p.res1, p.res1_dtype, ro + j);
-                        }
-                }
-                if (p.res2) {
-                    const int64_t ro = opix * p.res2_ld + co;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < nv) v[j] += load_elem(p.res2, p.res2_dtype, ro + j);
-                }
-                const int64_t oo = opix * p.out_ld + co;
-                if (nv == 4 && p.out_dtype == DSVC_F32 && ((((uintptr_t)p.out >> 2) + oo) & 3) == 0) {
-                    *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
-                } else if (nv == 4 && p.out_dtype == DSVC_BF16 && ((((uintptr_t)p.out >> 1) + oo) & 3) == 0) {
-                    uint2 u;
-                    u.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                    u.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-                    *(uint2*)((unsigned short*)p.out + oo) = u;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < nv) store_elem(p.out, p.out_dtype, oo + j, v[j]);
-                }
-            } else {  // PixelShuffle(2): conv channel co+j = cq*4 + dy*2 + dx  (co % 4 == 0, Cout % 4 == 0)
-                const int cq = co >> 2;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int dy = j >> 1, dx = j & 1;
-                    const int64_t spix = ((int64_t)b * (2 * p.Ho) + 2 * oy + dy) * (2 * p.Wo) + 2 * ox + dx;
-                    float o = v[j];
-                    if (p.res1) o += load_elem(p.res1, p.res1_dtype, spix * p.res1_ld + cq);
-                    store_elem(p.out, p.out_dtype, spix * p.out_ld + cq, o);
-                }
-            }
-        }
+        run_epilogue<GPP, EPLD, MT * 32>(p, R, slab, lane, b, oy0 + wave * MT, ox0, ng * NTN + n0 * 32, cpass);
     }
 }
 
-template <typename CT, int MT, int NT>
+template <typename CT, int MT, int NT, bool FAST>
 int launch_cfg(hipStream_t st, const ConvParams& p, int ngroups, size_t lds) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<CT, MT, NT>;
+    auto kern = conv_mfma_kernel<CT, MT, NT, FAST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
@@ -311,14 +240,20 @@ int launch_cfg(hipStream_t st, const ConvParams& p, int ngroups, size_t lds) {
     return DSVC_OK;
 }
 
-template <typename CT, int MT>
+template <typename CT, int MT, bool FAST>
 int launch_nt(hipStream_t st, const ConvParams& p, int NT, int ngroups, size_t lds) {
     switch (NT) {
-        case 1: return launch_cfg<CT, MT, 1>(st, p, ngroups, lds);
-        case 2: return launch_cfg<CT, MT, 2>(st, p, ngroups, lds);
-        case 3: return launch_cfg<CT, MT, 3>(st, p, ngroups, lds);
-        default: return launch_cfg<CT, MT, 4>(st, p, ngroups, lds);
+        case 1: return launch_cfg<CT, MT, 1, FAST>(st, p, ngroups, lds);
+        case 2: return launch_cfg<CT, MT, 2, FAST>(st, p, ngroups, lds);
+        case 3: return launch_cfg<CT, MT, 3, FAST>(st, p, ngroups, lds);
+        default: return launch_cfg<CT, MT, 4, FAST>(st, p, ngroups, lds);
     }
+}
+
+template <typename CT>
+int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, int ngroups, size_t lds) {
+    if (fast) return MT == 2 ? launch_nt<CT, 2, true>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, true>(st, p, NT, ngroups, lds);
+    return MT == 2 ? launch_nt<CT, 2, false>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, false>(st, p, NT, ngroups, lds);
 }
 
 inline int chunk_elems(int compute) { return compute == DSVC_F32 ? 16 : 32; }
@@ -354,8 +289,10 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
         DSVC_REQUIRE(in.ptr && in.C > 0 && in.ld >= in.C, "conv2d: segment %d ptr/C/ld invalid (C=%d ld=%d)", s, in.C, in.ld);
         DSVC_REQUIRE(in.dtype == DSVC_F32 || in.dtype == DSVC_BF16, "conv2d: segment %d dtype", s);
         const int es = dsvc_esize(in.dtype);
+        const int64_t ext = (((int64_t)d->B * d->H * d->W - 1) * in.ld + in.C) * es;
+        DSVC_REQUIRE(ext < 0x7FFFFFF0ll, "conv2d: input segment %d spans %lld bytes (limit 2 GiB)", s, (long long)ext);
         p.seg[s] = ConvSeg{in.ptr, in.C, in.ld, in.dtype,
-                           (int)((((uintptr_t)in.ptr & 15) == 0) && (((int64_t)in.ld * es) % 16 == 0)), chunk0};
+                           (int)((((uintptr_t)in.ptr & 15) == 0) && (((int64_t)in.ld * es) % 16 == 0)), chunk0, (unsigned)ext};
         chunk0 += (in.C + kce - 1) / kce;
     }
     p.nseg = d->nseg; p.nchunks = chunk0;
@@ -370,7 +307,34 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     p.res1 = d->res1; p.res1_ld = d->res1_ld; p.res1_dtype = d->res1_dtype; p.res1_scale = d->res1_scale;
     p.res2 = d->res2; p.res2_ld = d->res2_ld; p.res2_dtype = d->res2_dtype;
     p.out = d->out; p.out_ld = d->out_ld; p.out_dtype = d->out_dtype; p.shuffle = d->shuffle;
+    // 4-channel vector access (16 B fp32 / 8 B bf16) is legal when base and pixel pitch keep that alignment
+    auto vec4_ok = [](const void* ptr, int ld, int dtype) {
+        const int bytes = 4 * dsvc_esize(dtype);
+        return ptr != nullptr && ((uintptr_t)ptr % bytes) == 0 && (ld % 4) == 0;
+    };
+    p.res1_vec = vec4_ok(d->res1, d->res1_ld, d->res1_dtype);
+    p.res2_vec = vec4_ok(d->res2, d->res2_ld, d->res2_dtype);
+    p.out_vec = vec4_ok(d->out, d->out_ld, d->out_dtype);
+    {
+        const int sh = d->shuffle;
+        const int64_t opix = (int64_t)d->B * p.Ho * sh * p.Wo * sh, oc = d->Cout / (sh * sh);
+        const int64_t oe = ((opix - 1) * d->out_ld + oc) * dsvc_esize(d->out_dtype);
+        const int64_t r1e = d->res1 ? ((opix - 1) * d->res1_ld + oc) * dsvc_esize(d->res1_dtype) : 0;
+        const int64_t r2e = d->res2 ? ((opix - 1) * d->res2_ld + oc) * dsvc_esize(d->res2_dtype) : 0;
+        DSVC_REQUIRE(oe < 0x7FFFFFF0ll && r1e < 0x7FFFFFF0ll && r2e < 0x7FFFFFF0ll, "conv2d: output/residual tensor above 2 GiB");
+        p.out_bytes = (unsigned)oe; p.res1_bytes = (unsigned)r1e; p.res2_bytes = (unsigned)r2e;
+        p.epi_vec = d->shuffle == 1 && (d->Cout % 4) == 0 && p.out_vec && (!d->res1 || p.res1_vec) && (!d->res2 || p.res2_vec);
+    }
+    bool fast = true;
+    for (int s = 0; s < d->nseg; ++s)
+        fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == d->compute && (p.seg[s].C % kce) == 0;
 
+    // ---- bf16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
+    static const bool ws_enabled = getenv("DSVC_NO_WS") == nullptr;
+    if (ws_enabled) {
+        const int rc = dsvc_conv3x3_ws_try((hipStream_t)stream, p, d);
+        if (rc != 1) return rc;   // 1 = not applicable, fall through to the generic kernel
+    }
     // ---- tile configuration ----
     const int ntiles32 = p.Np / 32;
     int NT = ntiles32 >= 4 ? 4 : ntiles32;           // 1,2,3,4 (96 ch -> 3)
@@ -398,7 +362,6 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     DSVC_REQUIRE(lds <= 160 * 1024, "conv2d: LDS need %zu exceeds 160 KiB", lds);
 
     hipStream_t st = (hipStream_t)stream;
-    if (d->compute == DSVC_F32)
-        return MT == 2 ? launch_nt<float, 2>(st, p, NT, ngroups, lds) : launch_nt<float, 1>(st, p, NT, ngroups, lds);
-    return MT == 2 ? launch_nt<__bf16, 2>(st, p, NT, ngroups, lds) : launch_nt<__bf16, 1>(st, p, NT, ngroups, lds);
+    if (d->compute == DSVC_F32) return launch_ct<float>(st, p, MT, NT, fast, ngroups, lds);
+    return launch_ct<__bf16>(st, p, MT, NT, fast, ngroups, lds);
 }

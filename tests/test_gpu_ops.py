@@ -117,6 +117,32 @@ def test_conv_slices_shuffle_and_bf16_storage():
     report_close("bf16 storage", got.nchw().cpu(), want, 1e-2, 1e-2)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 250, 1100), (64, 32, 256, 1024), (64, 3, 264, 1000), (32, 64, 250, 1090), (32, 3, 256, 1056), (3, 64, 250, 1100)])
+def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
+    """Large-image bf16 3x3 convs take the persistent weight-stationary kernel (csrc/conv3x3_ws.hip):
+    ragged right/bottom tiles, the fused pre-activation, activation, both residuals and bf16 stores."""
+    from deepsvc_amd import _native as N, ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(cin * 100 + cout)
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(cin, cout, 3, 1, 1).to(DEV)
+        x, r1, r2 = torch.randn(1, cin, H, W), torch.randn(1, cout, H, W), torch.randn(1, cout, H, W)
+        bf = torch.bfloat16
+        plain = m.run(_act(x, bf), out_dtype=torch.float32).nchw().cpu()
+        fused = m.run(_act(x, bf), pre_act=N.ACT_LRELU, act=N.ACT_LRELU, slope=0.01, res1=_act(r1, bf), res2=_act(r2, bf),
+                      out_dtype=bf).nchw().cpu()
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    xb = x.to(bf).float()
+    want = F.conv2d(xb, w, b, padding=1)
+    report_close("rs plain", plain, want, 5e-3, 5e-3 * float(want.abs().max()))
+    pre = F.leaky_relu(xb, 0.01).to(bf).float()
+    want2 = F.leaky_relu(F.conv2d(pre, w, b, padding=1), 0.01) + r1.to(bf).float() + r2.to(bf).float()
+    report_close("rs fused", fused, want2, 2e-2, 2e-2 * float(want2.abs().max()))
+
+
 def test_warp_matches_grid_sample():
     from deepsvc_amd import ops
     from oracle import nets
