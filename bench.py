@@ -144,11 +144,18 @@ def main():
         durs = [a.elapsed_time(b) for a, b in prof["pairs"]]          # ms, HIP events on the launch stream
         conv_flop = 2.0 * H_pad * W_pad * 64 * 64 * 9
         roof = None
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")
+        if args.precision == "bf16" and (h, w) == (1080, 1920) and os.path.exists(pmc_file):
+            with open(pmc_file) as f:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (cannot run in-process)
+                traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
+            traffic_src = "profiles/r01_dominant_kernel_pmc.json (2*FETCH_SIZE + WRITE_SIZE per launch, MI355X_MICROARCH.md HBM correction)"
         if durs:
             avg_ms = sum(durs) / len(durs)
             achieved = conv_flop / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
+                    "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes": 2.0 * H_pad * W_pad * 64 * (2 if args.precision == "bf16" else 4),
                     "kernel": "conv_mfma_kernel 3x3 s1 64->64 @%dx%d" % (H_pad, W_pad), "launches": len(durs), "avg_ms": avg_ms}
         summ = harness.summarise(table)
         line = {

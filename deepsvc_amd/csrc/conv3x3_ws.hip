@@ -148,26 +148,31 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(const ConvParams p, 
             __builtin_amdgcn_sched_barrier(0);                   // hipcc otherwise sinks these loads below the MFMA phase
 
             const char* wt = lds_w + (size_t)ch * 9 * NTN * ROWB;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            // 18 k-steps (9 taps x 2 halves of the 64-B chunk), fragments of step s+1 are read before the MFMAs of step s
+            auto read_frags = [&](int s, uint4 (&af)[2], uint4 (&bf)[NT]) {
+                const int t = s >> 1, ks = s & 1;
                 const int tap_off = ((t / 3) * WS_PW + (t % 3)) * ROWB;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    uint4 af[2], bf[NT];
+                for (int n = 0; n < NT; ++n) bf[n] = *(const uint4*)(wt + t * NTN * ROWB + b_off[n] + ks * 16);
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) bf[n] = *(const uint4*)(wt + t * NTN * ROWB + b_off[n] + ks * 16);
+                for (int m = 0; m < 2; ++m) af[m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
+            };
+            uint4 af[2][2], bf[2][NT];
+            read_frags(0, af[0], bf[0]);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
+            for (int s2 = 0; s2 < 18; ++s2) {
+                if (s2 + 1 < 18) read_frags(s2 + 1, af[(s2 + 1) & 1], bf[(s2 + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // pin: next step's LDS reads are issued BEFORE this step's MFMAs
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[m]),
-                                                                                 __builtin_bit_cast(bf16x8, bf[n]), acc[m][n], 0, 0, 0);
-                }
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s2 & 1][m]),
+                                                                             __builtin_bit_cast(bf16x8, bf[s2 & 1][n]), acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 
-            __syncthreads();                                     // every wave is done reading this chunk's patch
+            lds_barrier();                                       // every wave is done reading this chunk's patch
             if (last) {                                          // epilogue through slabs that alias the patch buffer
                 int b, oy0, ox0;
                 tile_origin(tile, b, oy0, ox0);
@@ -181,10 +186,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_ws_kernel(const ConvParams p, 
     }
                 WS_PASS(0, 0) WS_PASS(0, 1) WS_PASS(1, 0) WS_PASS(1, 1)
 #undef WS_PASS
-                __syncthreads();                                 // slabs are dead before the patch buffer is refilled
+                lds_barrier();                                   // slabs are dead before the patch buffer is refilled
             }
             store_chunk(pf);
-            __syncthreads();
+            lds_barrier();
         }
     }
 }

@@ -48,6 +48,14 @@ __device__ __forceinline__ uint4 buf_load16(rsrc_t r, unsigned off) {
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the vector-memory queue, so
+// prefetch loads and epilogue stores stay in flight across it (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 struct EpiRsrc {      // one descriptor per operand (an absent residual borrows the output's; its offsets are all OOB)
     rsrc_t out, r1, r2;
     bool out_f32, r1_f32, r1_bf16, r2_f32, r2_bf16;
@@ -170,18 +178,21 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
             if (p.res1_scale) gate[j] = p.res1_scale[(int64_t)b * p.Cout + co + j];
         }
     }
+    // Address math: the pixel row / column start of iteration `it` is wave-uniform (scalar unit); each lane only adds
+    // its constant (lane / GPP) * ld + co.  No per-lane multiplies inside the loop.
     constexpr int STEP = 64 / GPP;
-#pragma unroll 4
-    for (int it = 0; it < NPL / STEP; ++it) {   // 4 iterations in flight: enough to overlap the residual loads
-        const int pl = lane / GPP + it * STEP;
-        const int oy = oy_base + (pl >> 5), ox = ox0 + (pl & 31);
-        const bool ok = lane_ok && oy < p.Ho && ox < p.Wo;
-        const unsigned opix = ((unsigned)b * p.Ho + oy) * p.Wo + ox;
-        const float4 a4 = *(const float4*)(slab + pl * EPLD + g * 4);
+    const int lp = lane / GPP;
+    const unsigned lane_o = (unsigned)lp * p.out_ld + co, lane_1 = (unsigned)lp * p.res1_ld + co, lane_2 = (unsigned)lp * p.res2_ld + co;
+#pragma unroll 2
+    for (int it = 0; it < NPL / STEP; ++it) {   // 2 iterations in flight overlap the residual loads at modest register cost
+        const int oy = oy_base + ((it * STEP) >> 5), xs = ox0 + ((it * STEP) & 31);   // scalars
+        const bool ok = lane_ok && oy < p.Ho && xs + lp < p.Wo;
+        const unsigned spix = ((unsigned)b * p.Ho + oy) * p.Wo + xs;                    // scalar
+        const float4 a4 = *(const float4*)(slab + (lp + it * STEP) * EPLD + g * 4);
         float v[4] = {act_t<ACT>(a4.x + bias[0], p.slope), act_t<ACT>(a4.y + bias[1], p.slope),
                       act_t<ACT>(a4.z + bias[2], p.slope), act_t<ACT>(a4.w + bias[3], p.slope)};
         if constexpr (HAS_RES) {
-            const unsigned e1 = opix * p.res1_ld + co, e2 = opix * p.res2_ld + co;
+            const unsigned e1 = spix * p.res1_ld + lane_1, e2 = spix * p.res2_ld + lane_2;
             const v4u_t f1 = __builtin_amdgcn_raw_buffer_load_b128(R.r1, (ok && R.r1_f32) ? e1 * 4 : OOB, 0, 0);
             const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_bf16) ? e1 * 2 : OOB, 0, 0);
             const v4u_t f2 = __builtin_amdgcn_raw_buffer_load_b128(R.r2, (ok && R.r2_f32) ? e2 * 4 : OOB, 0, 0);
@@ -200,7 +211,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += gate[j] * r1[j] + r2[j];
         }
-        const unsigned eo = opix * p.out_ld + co;
+        const unsigned eo = spix * p.out_ld + lane_o;
         v4u_t of;
         of.x = __builtin_bit_cast(unsigned, v[0]); of.y = __builtin_bit_cast(unsigned, v[1]);
         of.z = __builtin_bit_cast(unsigned, v[2]); of.w = __builtin_bit_cast(unsigned, v[3]);

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         const ConvSeg& sg = p.seg[s];
         const int c0 = (ch - sg.chunk0) * KCE;
 
-        __syncthreads();  // all waves done with the previous chunk's LDS contents
+        lds_barrier();  // all waves done with the previous chunk's LDS contents (LDS-only: global traffic stays in flight)
         // ---- stage the input halo patch of this channel chunk ----
         // Loads of a batch are all issued before the first LDS store so their L2/HBM latencies overlap.
         if constexpr (FAST) {  // storage type == compute type, 16-B aligned, whole chunks
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         int ky = 0, kx = 0;
         for (int tg0 = 0; tg0 < ntaps; tg0 += p.tapg) {
             const int tcur = min(p.tapg, ntaps - tg0);
-            if (tg0 > 0) __syncthreads();
+            if (tg0 > 0) lds_barrier();
             // ---- stage the weights of taps [tg0, tg0+tcur) for this chunk and N group (batched loads) ----
             {
                 constexpr int WB = 9;
@@ -165,36 +165,58 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                         if (base + 64 * j < nrows) *(uint4*)(lds_w + (base + 64 * j) * ROWB + q * 16) = v[j];
                 }
             }
-            __syncthreads();
+            lds_barrier();
 
-            for (int t = 0; t < tcur; ++t) {
+            // ---- MFMA phase, software-pipelined over taps: while the MFMAs of one tap run, the LDS reads of the next
+            // tap are already in flight.  Two named fragment sets (static register indexing), branch-free loop body
+            // (the trailing prefetch re-reads the last tap), scheduling barriers pin the read-before-MFMA order.
+            struct Frags { uint4 a[2][MT], b[2][NT]; };
+            int rt = 0;                                   // next tap (within the staged group) to read
+            auto read_tap = [&](Frags& f) {
                 const int tap_off = (ky * PW + kx) * ROWB;
-                const char* wt = lds_w + t * NTN * ROWB;
+                const char* wt = lds_w + rt * NTN * ROWB;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    uint4 af[MT], bf[NT];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) bf[n] = *(const uint4*)(wt + b_off[n] + ks * 16);
+                    for (int n = 0; n < NT; ++n) f.b[ks][n] = *(const uint4*)(wt + b_off[n] + ks * 16);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) af[m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
+                    for (int m = 0; m < MT; ++m) f.a[ks][m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
+                }
+                if (rt + 1 < tcur) { ++rt; if (++kx == p.kw) { kx = 0; ++ky; } }
+            };
+            auto mfma_tap = [&](const Frags& f) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
                             if constexpr (sizeof(CT) == 4) {
-                                const f32x4 a4 = __builtin_bit_cast(f32x4, af[m]);
-                                const f32x4 b4 = __builtin_bit_cast(f32x4, bf[n]);
+                                const f32x4 a4 = __builtin_bit_cast(f32x4, f.a[ks][m]);
+                                const f32x4 b4 = __builtin_bit_cast(f32x4, f.b[ks][n]);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j)
                                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[m][n], 0, 0, 0);
                             } else {
                                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(bf16x8, af[m]), __builtin_bit_cast(bf16x8, bf[n]), acc[m][n], 0, 0, 0);
+                                    __builtin_bit_cast(bf16x8, f.a[ks][m]), __builtin_bit_cast(bf16x8, f.b[ks][n]), acc[m][n], 0, 0, 0);
                             }
                         }
-                }
-                if (++kx == p.kw) { kx = 0; ++ky; }
+            };
+            Frags fA, fB;
+            read_tap(fA);
+            for (int i = 0; i < (tcur >> 1); ++i) {
+                read_tap(fB);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tap(fA);
+                __builtin_amdgcn_sched_barrier(0);
+                read_tap(fA);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tap(fB);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (tcur & 1) mfma_tap(fA);
+            if (++kx == p.kw) { kx = 0; ++ky; }            // step past the group's last tap for the next group
         }
     }
 
@@ -208,7 +230,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     const EpiRsrc R = make_epi_rsrc(p);
 #pragma unroll
     for (int n0 = 0; n0 < NT; n0 += EPN) {
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int e = 0; e < EPN; ++e) {
             if (n0 + e < NT) {
@@ -219,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                         slab[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[m][n0 + e < NT ? n0 + e : 0][i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
         run_epilogue<GPP, EPLD, MT * 32>(p, R, slab, lane, b, oy0 + wave * MT, ox0, ng * NTN + n0 * 32, cpass);
     }

@@ -1,0 +1,86 @@
+"""CPU tests of the harness: GOP sharding, metric gather across 2 processes (gloo), GOP loop state chaining.
+The codec itself is replaced by a stub here (the product has no CPU compute path); the chaining contract checked is
+the one of test_video.py:332-369: key frame resets (ref, feature), every P-frame hands (recon, feature) to the next."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+from deepsvc_amd import harness
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_units_partition():
+    for n, w in ((64, 8), (7, 2), (3, 4), (0, 2)):
+        shards = [harness.shard_units(n, r, w) for r in range(w)]
+        flat = sorted(u for s in shards for u in s)
+        assert flat == list(range(n))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+class _StubCodec:
+    """Records the call sequence; 'recon' = cur * 0.5 so PSNR is finite and state chaining is observable."""
+
+    def __init__(self):
+        self.calls = []
+
+    def compress(self, ref, cur, sm, feature):
+        self.calls.append(("c", float(ref.mean()), None if feature is None else float(feature.mean())))
+        return ({"strings": [[b"\x00" * 10], [b"\x00" * 6]], "shape": (1, 1)}, {"strings": [[b"\x00" * 20], [b"\x00" * 4]], "shape": (1, 1)})
+
+    def decompress(self, ref, mv, res, sm, feature):
+        self.calls.append(("d", float(ref.mean()), None if feature is None else float(feature.mean())))
+        recon = ref * 0.5
+        return torch.full((1, 64, 1, 1), float(len(self.calls))), recon, recon, recon
+
+
+def test_code_gop_chains_state_and_measures():
+    frames = [torch.full((1, 3, 60, 100), 0.8) for _ in range(4)]     # un-padded 60x100 -> padded 64x128
+    sms = [None] + [torch.zeros(1, 256, 16, 32) for _ in range(3)]
+    codec = _StubCodec()
+    rows = harness.code_gop(codec, frames, sms, unit=5)
+    assert len(rows) == 3 and all(len(r) == len(harness.METRIC_COLUMNS) for r in rows)
+    assert [r[0] for r in rows] == [5.0] * 3 and [r[1] for r in rows] == [1.0, 2.0, 3.0]
+    # bpp uses the UN-padded pixel count (test_video.py:295,364-366): (10+6)*8/(60*100), (20+4)*8/(60*100)
+    assert abs(rows[0][2] - 16 * 8 / 6000) < 1e-12 and abs(rows[0][3] - 24 * 8 / 6000) < 1e-12
+    # first P-frame sees feature=None, later ones the feature returned by the previous decompress; ref halves each time
+    assert codec.calls[0][2] is None and codec.calls[1][2] is None
+    assert codec.calls[2][2] == 2.0 and codec.calls[4][2] == 4.0
+    assert codec.calls[2][1] < codec.calls[0][1]
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+from deepsvc_amd import harness
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+units = harness.shard_units(5, rank, world)          # 5 GOPs over 2 ranks: ranks get 3 and 2 -> ragged gather
+rows = [[float(u), float(t), 0.1 * u, 0.2, 30.0 + u, 0, 0, 0.01, 0.02] for u in units for t in (1, 2)]
+table = harness.gather_rows(rows, torch.device("cpu"), world)
+assert table.shape == (10, len(harness.METRIC_COLUMNS)), table.shape
+assert sorted(set(table[:, 0].tolist())) == [0.0, 1.0, 2.0, 3.0, 4.0]
+s = harness.summarise(table)
+assert s["frames"] == 10 and abs(s["ppsnr"] - 32.0) < 1e-9
+print("rank", rank, "ok", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gather_gloo(tmp_path):
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
