@@ -41,7 +41,8 @@ class Operand(Structure):
 
 
 class CdfTable(Structure):
-    _fields_ = [("cdf", c_void_p), ("rows", c_int32), ("stride", c_int32), ("cdf_length", c_void_p), ("offset", c_void_p)]
+    _fields_ = [("cdf", c_void_p), ("rows", c_int32), ("stride", c_int32), ("cdf_length", c_void_p), ("offset", c_void_p),
+                ("lut", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol of include/dsvc.h is listed (tests check this against the header)
@@ -76,6 +77,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_int32, c_void_p, c_int32]),
     "dsvc_eb_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32]),
     "dsvc_pmf_to_quantized_cdf": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    "dsvc_cdf_build_lut": (c_int, [POINTER(CdfTable), c_void_p]),
     "dsvc_rans_encoder_create": (c_int, [POINTER(c_void_p)]),
     "dsvc_rans_encoder_destroy": (None, [c_void_p]),
     "dsvc_rans_encode_with_indexes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(CdfTable)]),

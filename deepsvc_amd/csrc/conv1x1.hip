@@ -1,0 +1,129 @@
+// conv1x1.hip -- bf16 pointwise (1x1) convolution as a pure streaming kernel (ResBottleneck conv1/conv3,
+// ConvBlockResidual.up_dim: modules.py:176,178,242; image_model.py:25,27).
+//
+// A 1x1 conv has no halo, so nothing is reused across pixels except the weights: HBM-bound (2 bytes in + 2 bytes
+// out per MAC-column).  Structure for that regime:
+//   * the image is a flat list of pixels; a wave owns 32 consecutive pixels at a time (grid-stride, persistent waves);
+//   * the MFMA A fragments are loaded STRAIGHT from HBM in operand layout -- lane (r,h) reads the 16 B holding channels
+//     [16ks+8h, +8) of pixel r -- with bounds-checked buffer loads (the ragged tail reads zeros); no LDS staging, no
+//     workgroup barriers; the next unit's fragments are in flight while the current unit's MFMAs and stores run;
+//   * the weights (<= 128x128) live in registers as B fragments for the whole launch;
+//   * the epilogue is the shared fused pass (bias, activation, gated residual, second residual, cast) through a
+//     wave-private LDS slab so that stores are 16-B vectors along the NHWC channel axis.
+#include "conv_common.h"
+
+using namespace dsvc_conv;
+
+namespace {
+
+template <int KS, int NT>
+__global__ void __launch_bounds__(256) conv1x1_kernel(const ConvParams p, int nunits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPN = NT >= 2 ? 2 : 1;
+    constexpr int EPLD = EPN * 32 + 4, GPP = EPN * 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    float* slab = (float*)smem + wave * (32 * EPLD);
+    const EpiRsrc R = make_epi_rsrc(p);
+    const rsrc_t rin = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
+    const unsigned pitch = (unsigned)p.seg[0].ld * 2;
+    const unsigned npix = (unsigned)p.Wo;                      // host presents the tensor as one row of B*H*W pixels
+
+    // weights -> registers (packed layout [chunk][tap=1][Np][64 B])
+    uint4 wreg[KS][NT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 32 + r;
+            wreg[ks][n] = co < p.Np ? *(const uint4*)((const char*)p.w + ((size_t)(ks >> 1) * p.Np + co) * 64 + (ks & 1) * 32 + h * 16)
+                                    : make_uint4(0, 0, 0, 0);
+        }
+
+    const int nwaves = gridDim.x * 4;
+    int unit = blockIdx.x * 4 + wave;
+    auto load_a = [&](int u, uint4 (&a)[KS]) {
+        const unsigned pix = (unsigned)u * 32 + r;
+        const unsigned base = pix < npix && u < nunits ? pix * pitch + h * 16 : OOB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = buf_load16(rin, base == OOB ? OOB : base + ks * 32);
+    };
+    uint4 a_cur[KS], a_nxt[KS];
+    load_a(unit, a_cur);
+    for (; unit < nunits; unit += nwaves) {
+        load_a(unit + nwaves, a_nxt);                          // prefetch (reads zeros past the end)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[ks]),
+                                                                 __builtin_bit_cast(bf16x8, wreg[ks][n]), acc[n], 0, 0, 0);
+        // epilogue: <= 2 N-tiles per pass through the wave-private slab
+#define C1_PASS(N0)                                                                                                  \
+    if constexpr (N0 < NT) {                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < EPN; ++e) {                                                            \
+            if (N0 + e < NT) {                                                                                       \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                       \
+                    slab[((i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[N0 + e < NT ? N0 + e : 0][i];  \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+        run_epilogue<GPP, EPLD, 32>(p, R, slab, lane, 0, 0, unit * 32, N0 * 32, (NT - N0 < EPN ? NT - N0 : EPN) * 32); \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+    }
+        C1_PASS(0) C1_PASS(2)
+#undef C1_PASS
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+    }
+}
+
+template <int KS, int NT>
+int launch_1x1(hipStream_t st, const ConvParams& p, int nunits) {
+    constexpr int EPN = NT >= 2 ? 2 : 1;
+    const size_t lds = (size_t)4 * 32 * (EPN * 32 + 4) * sizeof(float);
+    int grid = (nunits + 3) / 4;
+    if (grid > 256 * 4) grid = 256 * 4;                        // 4 workgroups (16 waves) per CU, grid-stride beyond
+    hipLaunchKernelGGL((conv1x1_kernel<KS, NT>), dim3(grid), dim3(256), lds, st, p, nunits);
+    DSVC_CHECK_LAUNCH("conv1x1_kernel");
+    return DSVC_OK;
+}
+
+template <int KS>
+int launch_1x1_nt(hipStream_t st, const ConvParams& p, int nunits, int NT) {
+    switch (NT) {
+        case 1: return launch_1x1<KS, 1>(st, p, nunits);
+        case 2: return launch_1x1<KS, 2>(st, p, nunits);
+        case 3: return launch_1x1<KS, 3>(st, p, nunits);
+        default: return launch_1x1<KS, 4>(st, p, nunits);
+    }
+}
+
+}  // namespace
+
+// returns 1 when the shape is not covered (caller falls back to the generic kernel), else DSVC_OK / error
+int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
+    if (d->compute != DSVC_BF16 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->shuffle != 1) return 1;
+    if (d->nseg != 1 || d->pre_act != DSVC_ACT_NONE || !p_in.epi_vec || (d->res1_scale && d->B > 1)) return 1;
+    const ConvSeg& sg = p_in.seg[0];
+    if (sg.dtype != DSVC_BF16 || !sg.vec_ok || (sg.C % 32) != 0 || sg.C > 128 || d->Cout > 128) return 1;
+    const int64_t npix = (int64_t)d->B * d->H * d->W;
+    if (npix < 64 * 1024) return 1;                            // small images stay on the generic kernel
+    ConvParams p = p_in;
+    p.B = 1; p.Ho = 1; p.Wo = (int)npix;                        // flat pixel list: offsets are pixel-linear
+    const int nunits = (int)((npix + 31) / 32);
+    const int NT = (d->Cout + 31) / 32;
+    switch (sg.C / 16) {
+        case 2: return launch_1x1_nt<2>(st, p, nunits, NT);
+        case 4: return launch_1x1_nt<4>(st, p, nunits, NT);
+        case 6: return launch_1x1_nt<6>(st, p, nunits, NT);
+        default: return launch_1x1_nt<8>(st, p, nunits, NT);
+    }
+}

@@ -24,6 +24,7 @@
 #include "conv_common.h"
 
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 namespace {
 using namespace dsvc_conv;
@@ -353,6 +354,10 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
 
     // ---- bf16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
     static const bool ws_enabled = getenv("DSVC_NO_WS") == nullptr;
+    if (ws_enabled) {   // bf16 pointwise convs: streaming kernel, no LDS staging
+        const int rc = dsvc_conv1x1_try((hipStream_t)stream, p, d);
+        if (rc != 1) return rc;
+    }
     if (ws_enabled) {
         const int rc = dsvc_conv3x3_ws_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;   // 1 = not applicable, fall through to the generic kernel

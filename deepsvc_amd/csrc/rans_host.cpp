@@ -7,11 +7,16 @@
 // 16-bit probabilities, out-of-range symbols escaped through 4-bit bypass nibbles; symbols are
 // pushed in order and coded in reverse; the stream is the little-endian word sequence.
 //
-// Implementation notes (differs from the straightforward form on purpose):
+// Implementation notes (differs from the straightforward form on purpose; bytes are identical by construction
+// and checked against the oracle's plain restatement in tests/test_cabi_host.py):
 //   * the pending list stores one packed 32-bit entry per coded item (start:16 | (range-1):16,
 //     bypass items tagged by an out-of-band bitmap) -- half the memory traffic of a struct list;
-//   * the decoder's symbol search is a branch-light binary search over the CDF row instead of a
-//     linear scan (rows reach 3133 entries for sigma = 256); results are identical by construction.
+//   * ENCODE never divides: x / freq is a 64x64->128 multiply by a per-frequency reciprocal (the ryg_rans
+//     Rans64EncSymbolInit construction, exact for every state the coder can reach), table built once per process;
+//   * DECODE finds the symbol through a per-row 256-entry lookup table indexed by the top 8 bits of the 16-bit
+//     cumulative frequency (first candidate symbol), then a short forward scan -- rows reach 3133 entries for
+//     sigma = 256 but the probability mass sits in a few symbols, so the scan is ~1 step; the LUT belongs to the
+//     caller's dsvc_cdf_table (dsvc_cdf_build_lut); without one the decoder binary-searches.
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -23,6 +28,33 @@ constexpr uint32_t kPrecision = 16;
 constexpr uint32_t kBypassBits = 4;
 constexpr int32_t kBypassMax = 15;
 constexpr uint64_t kRansL = 1ull << 31;
+
+// ---- division-free encode: q = mulhi(x, rcp) >> shift == x / freq for all x < 2^63 (ryg_rans rans64.h) ----------
+struct Rcp { uint64_t rcp; uint32_t shift; };
+static Rcp g_rcp[65537];
+static bool g_rcp_ready = false;
+static void init_rcp() {
+    if (g_rcp_ready) return;
+    g_rcp[0] = Rcp{0, 0};
+    g_rcp[1] = Rcp{~0ull, 0};               // freq 1: handled separately (q = x)
+    for (uint32_t freq = 2; freq <= 65536; ++freq) {
+        uint32_t shift = 0;
+        while (freq > (1u << shift)) ++shift;
+        // ((2^(shift+63)) + freq-1) / freq by two 64-bit divides
+        uint64_t x0 = freq - 1, x1 = 1ull << (shift + 31);
+        const uint64_t t1 = x1 / freq;
+        x0 += (x1 % freq) << 32;
+        const uint64_t t0 = x0 / freq;
+        g_rcp[freq] = Rcp{t0 + (t1 << 32), shift - 1};
+    }
+    g_rcp_ready = true;
+}
+static const bool g_rcp_init_at_load = (init_rcp(), true);   // built before any thread can encode
+static inline uint64_t div_by(uint64_t x, uint32_t freq) {
+    if (freq == 1) return x;
+    const Rcp& r = g_rcp[freq];
+    return (uint64_t)(((unsigned __int128)x * r.rcp) >> 64) >> r.shift;
+}
 
 struct Encoder {
     std::vector<uint32_t> items;   // start | (range-1) << 16
@@ -63,6 +95,7 @@ bool table_ok(const dsvc_cdf_table* t) {
 
 extern "C" int dsvc_rans_encoder_create(void** enc) {
     DSVC_REQUIRE(enc != nullptr, "rans_encoder_create: null out pointer");
+    init_rcp();
     *enc = new Encoder();
     return DSVC_OK;
 }
@@ -115,10 +148,11 @@ extern "C" int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap) {
             const uint32_t it = e->items[k];
             const uint32_t start = it & 0xFFFFu;
             if (!e->bypass[k]) {
-                const uint64_t freq = (uint64_t)(it >> 16) + 1;
-                const uint64_t x_max = ((kRansL >> kPrecision) << 32) * freq;
+                const uint32_t freq = (it >> 16) + 1;
+                const uint64_t x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)freq;
                 if (x >= x_max) { e->words[--p] = (uint32_t)x; x >>= 32; }
-                x = ((x / freq) << kPrecision) + (x % freq) + start;
+                const uint64_t q = div_by(x, freq);                           // x / freq without a divide
+                x = x + start + q * (uint64_t)((1u << kPrecision) - freq);     // == (q << 16) + x % freq + start
             } else {
                 const uint64_t x_max = ((kRansL >> 16) << 32) * (1ull << (16 - kBypassBits));
                 if (x >= x_max) { e->words[--p] = (uint32_t)x; x >>= 32; }
@@ -139,6 +173,22 @@ extern "C" int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap) {
     return nb;
 }
 
+extern "C" int dsvc_cdf_build_lut(const dsvc_cdf_table* t, uint16_t* lut_out) {
+    DSVC_REQUIRE(table_ok(t) && lut_out, "cdf_build_lut: bad argument");
+    for (int r = 0; r < t->rows; ++r) {
+        const int32_t* row = t->cdf + (int64_t)r * t->stride;
+        const int32_t len = t->cdf_length[r];
+        DSVC_REQUIRE(len >= 2 && len <= t->stride, "cdf_build_lut: cdf_length[%d] invalid", r);
+        int32_t s = 0;
+        for (int b = 0; b < 256; ++b) {
+            const uint32_t cf = (uint32_t)b << 8;
+            while (s + 1 < len - 1 && (uint32_t)row[s + 1] <= cf) ++s;   // largest s with row[s] <= cf
+            lut_out[(size_t)r * 256 + b] = (uint16_t)s;
+        }
+    }
+    return DSVC_OK;
+}
+
 extern "C" int dsvc_rans_decoder_create(void** dec, const uint8_t* data, int64_t nbytes) {
     DSVC_REQUIRE(dec && data && nbytes >= 8 && nbytes % 4 == 0, "rans_decoder_create: need >= 8 bytes, multiple of 4 (got %lld)", (long long)nbytes);
     Decoder* d = new Decoder();
@@ -156,6 +206,7 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
     DSVC_REQUIRE(dec && indexes && out && n >= 0, "rans_decode: null argument");
     DSVC_REQUIRE(table_ok(t), "rans_decode: bad cdf table");
     Decoder* d = (Decoder*)dec;
+    const uint16_t* lut = t->lut;
     for (int64_t i = 0; i < n; ++i) {
         const int32_t ci = indexes[i];
         DSVC_REQUIRE(ci >= 0 && ci < t->rows, "rans_decode: cdf index %d out of range at %lld", ci, (long long)i);
@@ -163,13 +214,20 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
         const int32_t len = t->cdf_length[ci];
         const int32_t max_value = len - 2;
         const uint32_t cf = (uint32_t)(d->x & 0xFFFFu);
-        // largest s in [0, len-2] with row[s] <= cf  (row[0] = 0, row[len-1] = 65536 > cf)
-        int32_t lo = 0, hi = len - 1;
-        while (hi - lo > 1) {
-            const int32_t mid = (lo + hi) >> 1;
-            if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
+        // largest s in [0, len-2] with row[s] <= cf  (row[0] = 0, row[len-1] = 65536 > cf):
+        // start from the LUT's answer for the bucket's first value, scan forward (usually 0-1 steps)
+        int32_t s;
+        if (lut) {
+            s = lut[(size_t)ci * 256 + (cf >> 8)];
+            while ((uint32_t)row[s + 1] <= cf) ++s;
+        } else {
+            int32_t lo = 0, hi = len - 1;
+            while (hi - lo > 1) {
+                const int32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
+            }
+            s = lo;
         }
-        const int32_t s = lo;
         const uint32_t start = (uint32_t)row[s], freq = (uint32_t)(row[s + 1] - row[s]);
         d->x = (uint64_t)freq * (d->x >> kPrecision) + cf - start;
         d->renorm();

@@ -11,6 +11,8 @@ API, attribute paths and bitstream format follow the reference; the execution do
   * the encoder derives y_hat/z_hat directly (`q + mu`) instead of entropy-decoding its own output
     (image_model.py:207, video_model.py:141) -- identical values, since every kernel involved is deterministic.
 """
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -22,6 +24,19 @@ from .modules import Conv2d, Deconv5x5s2, ResBottleneckBlock, conv, get_scale_ta
 from .ops import Act, to_act
 
 F32 = torch.float32
+_CODER_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="dsvc-rans")   # ctypes calls release the GIL
+
+
+class PendingStrings:
+    """Range coding of one codec's symbols running on a worker thread (it first waits for the async device->host
+    copy of the symbol planes); `.result()` joins and returns the reference-style {"strings", "shape"} dict."""
+
+    def __init__(self, future):
+        self._future = future
+
+    def result(self):
+        return self._future.result()
+
 
 
 def conv3x3(cin, cout, stride=1):
@@ -173,8 +188,8 @@ class ChannelSplitICIP2020ResB(nn.Module):
             self._lrp(i, means, y_hat)
         return self._g_s(y_hat, x_hat_out, x_hat_dtype), y_lik, z_lik
 
-    def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None):
-        """-> ({"strings", "shape"}, x_hat Act or None)."""
+    def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None, defer=False):
+        """-> ({"strings", "shape"} or PendingStrings when defer=True, x_hat Act or None)."""
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck
         y = self._g_a(segments)
         z = self._h_a(y)
@@ -194,14 +209,25 @@ class ChannelSplitICIP2020ResB(nn.Module):
                             sym_out=staging[nz + i * ns: nz + (i + 1) * ns],
                             idx_out=staging[nz + ny + i * ns: nz + ny + (i + 1) * ns])
             self._lrp(i, means, y_hat)
-        # the synthesis transform (if the caller needs it) is queued BEFORE the blocking copy so the GPU
-        # keeps working while the host range-codes
+        # Symbols leave the device through one async copy into pinned memory; the host range coder runs on a worker
+        # thread behind the copy's event, so the caller can keep queuing GPU work (synthesis transform, MC, ...).
+        host = torch.empty(staging.numel(), dtype=torch.int32, pin_memory=True)
+        host.copy_(staging, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        zB, zC, zH, zW = z.B, z.C, z.H, z.W
+
+        def encode():
+            done.synchronize()
+            packed = host.numpy()
+            z_strings = eb.encode_symbols(packed[:nz], zB, zC, zH, zW)
+            enc = ops.RansEncoder()
+            enc.encode_with_indexes(packed[nz:nz + ny], packed[nz + ny:], gc.host_tables())
+            return {"strings": [[enc.flush()], z_strings], "shape": (zH, zW)}
+
+        pending = PendingStrings(_CODER_POOL.submit(encode))
         x_hat = self._g_s(y_hat, None, x_hat_dtype) if want_x_hat else None
-        packed = staging.cpu().numpy()                               # one D2H transfer, one sync
-        z_strings = eb.encode_symbols(packed[:nz], z.B, z.C, z.H, z.W)
-        enc = ops.RansEncoder()
-        enc.encode_with_indexes(packed[nz:nz + ny], packed[nz + ny:], gc.host_tables())
-        return {"strings": [[enc.flush()], z_strings], "shape": (z.H, z.W)}, x_hat
+        return (pending if defer else pending.result()), x_hat
 
     def run_decompress(self, strings, shape, device, x_hat_out=None, x_hat_dtype=None):
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck
@@ -216,18 +242,26 @@ class ChannelSplitICIP2020ResB(nn.Module):
         dec = ops.RansDecoder(strings[0][0])
         k = self.max_support_slices
         groups = [[i] for i in range(min(k, self.num_slices))] + ([list(range(k, self.num_slices))] if self.num_slices > k else [])
+        n = B * d * h * w
+        gmax = max(len(g) for g in groups)
+        idx_dev = torch.empty(gmax * n, dtype=torch.int32, device=device)
+        sym_dev = torch.empty(gmax * n, dtype=torch.int32, device=device)
+        idx_host = torch.empty(gmax * n, dtype=torch.int32, pin_memory=True)     # pinned: async copies, no staging hop
+        sym_host = torch.empty(gmax * n, dtype=torch.int32, pin_memory=True)
+        stream = torch.cuda.current_stream(device)
         for group in groups:
-            mus, idx = [], []
-            for i in group:                      # parameter nets of a dependency level are queued together
+            mus = []
+            for j, i in enumerate(group):        # parameter nets of a dependency level are queued together
                 mu, sc = self._slice_params(i, means, scales, y_hat)
-                _, ix = ops.gc_quantize(None, mu, sc, table, False, True)
+                ops.gc_quantize(None, mu, sc, table, False, True, idx_out=idx_dev[j * n:(j + 1) * n])
                 mus.append(mu)
-                idx.append(ix)
-            idx_host = (torch.cat(idx) if len(idx) > 1 else idx[0]).cpu().numpy()   # sync point of this level
-            sym = torch.from_numpy(dec.decode_stream(idx_host, tables)).to(device)
-            n = B * d * h * w
+            m = len(group) * n
+            idx_host[:m].copy_(idx_dev[:m], non_blocking=True)
+            stream.synchronize()                 # the one sync point of this level
+            dec.decode_stream(idx_host.numpy()[:m], tables, out=sym_host.numpy()[:m])
+            sym_dev[:m].copy_(sym_host[:m], non_blocking=True)
             for j, i in enumerate(group):
-                ops.gc_dequantize(sym[j * n:(j + 1) * n], mus[j], y_hat.ch(i * d, d))
+                ops.gc_dequantize(sym_dev[j * n:(j + 1) * n], mus[j], y_hat.ch(i * d, d))
                 self._lrp(i, means, y_hat)
         return self._g_s(y_hat, x_hat_out, x_hat_dtype)
 

@@ -331,7 +331,10 @@ class CdfTables:
         self.cdf_length = np.ascontiguousarray(cdf_length, dtype=np.int32).reshape(-1)
         self.offset = np.ascontiguousarray(offset, dtype=np.int32).reshape(-1)
         self.c = N.CdfTable(self.cdf.ctypes.data, self.cdf.shape[0], self.cdf.shape[1],
-                            self.cdf_length.ctypes.data, self.offset.ctypes.data)
+                            self.cdf_length.ctypes.data, self.offset.ctypes.data, None)
+        self.lut = np.empty((self.cdf.shape[0], 256), dtype=np.uint16)          # decode accelerator, owned here
+        N.check(N.lib().dsvc_cdf_build_lut(byref(self.c), self.lut.ctypes.data), "cdf_build_lut")
+        self.c.lut = self.lut.ctypes.data
 
 
 def pmf_to_quantized_cdf(pmf, precision=16):
@@ -375,9 +378,12 @@ class RansDecoder:
         self.h = ctypes.c_void_p()
         N.check(N.lib().dsvc_rans_decoder_create(byref(self.h), data, len(data)), "rans_decoder_create")
 
-    def decode_stream(self, indexes, tables):
+    def decode_stream(self, indexes, tables, out=None):
+        """out: optional int32 numpy vector to decode into (e.g. the view of a pinned host tensor)."""
         i = np.ascontiguousarray(indexes, dtype=np.int32).reshape(-1)
-        out = np.empty(len(i), dtype=np.int32)
+        if out is None:
+            out = np.empty(len(i), dtype=np.int32)
+        assert out.dtype == np.int32 and out.size == i.size and out.flags["C_CONTIGUOUS"]
         N.check(N.lib().dsvc_rans_decode_stream(self.h, i.ctypes.data, len(i), byref(tables.c), out.ctypes.data), "rans_decode")
         return out
 

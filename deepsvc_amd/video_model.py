@@ -104,13 +104,14 @@ class DeepSVC(nn.Module):
         """video_model.py:137-151 -> (mv_out_enc, res_out_enc), each {"strings": [[y],[z...]], "shape": (h,w)}."""
         ref, cur = to_act(ref_frame), to_act(curr_frame)
         mv_est = self.opticFlow.run(cur, ref)
-        mv_enc, mv_coarse = self.mv_codec.run_compress([cur, mv_est, ref], want_x_hat=True, x_hat_dtype=F32)
+        # the mv streams are range-coded on a worker thread while the GPU runs prediction + the residual analysis
+        mv_pending, mv_coarse = self.mv_codec.run_compress([cur, mv_est, ref], want_x_hat=True, x_hat_dtype=F32, defer=True)
         _, _, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
         predict_fea = self.FeatureExtractor.run(predict)
         cur_fea = self.FeatureExtractor.run(cur)
         res = ops.eltwise(N.EW_SUB, cur_fea, predict_fea)
-        res_enc, _ = self.res_codec.run_compress([ref, res, predict])
-        return mv_enc, res_enc
+        res_pending, _ = self.res_codec.run_compress([ref, res, predict], defer=True)
+        return mv_pending.result(), res_pending.result()
 
     @torch.no_grad()
     def decompress(self, ref_frame, mv_out_enc, res_out_enc, sm_fea, feature):

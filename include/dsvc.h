@@ -188,7 +188,10 @@ typedef struct dsvc_cdf_table {
     int32_t rows, stride;
     const int32_t* cdf_length; /* [rows] */
     const int32_t* offset;     /* [rows] */
+    const uint16_t* lut;       /* optional [rows][256] decode accelerator from dsvc_cdf_build_lut, or NULL */
 } dsvc_cdf_table;
+/* lut_out[row*256 + b] = largest symbol s with cdf[row][s] <= (b << 8): the decoder starts its search there */
+int dsvc_cdf_build_lut(const dsvc_cdf_table* t, uint16_t* lut_out);
 
 /* BufferedRansEncoder (image_model.py:221,253-254) */
 int dsvc_rans_encoder_create(void** enc);

@@ -143,6 +143,31 @@ def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
     report_close("rs fused", fused, want2, 2e-2, 2e-2 * float(want2.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
+def test_conv1x1_streaming_kernel(cin, cout):
+    """Large bf16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,
+    activation, gated residual + second residual."""
+    from deepsvc_amd import _native as N, ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(cin + cout)
+    H, W = 250, 333              # 83250 pixels: not a multiple of 32
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(cin, cout, 1, 1, 0).to(DEV)
+        x, r1, r2 = torch.randn(1, cin, H, W), torch.randn(1, cout, H, W), torch.randn(1, cout, H, W)
+        gate = torch.rand(1, cout)
+        bf = torch.bfloat16
+        plain = m.run(_act(x, bf), act=N.ACT_LRELU, slope=0.01, out_dtype=torch.float32).nchw().cpu()
+        fused = m.run(_act(x, bf), res1=_act(r1, bf), gate=gate.to(DEV), res2=_act(r2), out_dtype=bf).nchw().cpu()
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    y = F.conv2d(x.to(bf).float(), w, b)
+    report_close("1x1 lrelu", plain, F.leaky_relu(y, 0.01), 5e-3, 5e-3 * float(y.abs().max()))
+    want = y + gate[:, :, None, None] * r1.to(bf).float() + r2
+    report_close("1x1 fused", fused, want, 2e-2, 2e-2 * float(want.abs().max()))
+
+
 def test_warp_matches_grid_sample():
     from deepsvc_amd import ops
     from oracle import nets
