@@ -248,6 +248,70 @@ __device__ __forceinline__ void run_epilogue(const ConvParams& p, const EpiRsrc&
 #undef DSVC_EPI_CASE
 }
 
+
+// ---- direct epilogue for the SWAPPED operand order (A = weights, B = pixels) -------------------------------------------
+// D[row = output channel][col = pixel]: lane (r = lane&31, h = lane>>5) owns pixel r of the M-tile and, per register
+// group g = reg>>2, the 4 consecutive channels cbase + 8g + 4h .. +3 -- exactly one 16-B (fp32) / 8-B (bf16) vector
+// of the NHWC output.  No LDS transposition, no barrier; straight-line buffer ops (masked lanes / absent operands via OOB).
+template <int ACT, bool HAS_RES>
+__device__ __forceinline__ void epilogue_direct_tile(const ConvParams& p, const EpiRsrc& R, const rsrc_t& rbias, const f32x16& acc,
+                                                     unsigned opix, bool pix_ok, int cbase, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co = cbase + 8 * g + 4 * h;
+        const bool ok = pix_ok && co < p.Cout;              // Cout % 4 == 0 on this path
+        const v4u_t bw = __builtin_amdgcn_raw_buffer_load_b128(rbias, co < p.Cout ? (unsigned)co * 4 : OOB, 0, 0);
+        const unsigned bu[4] = {bw.x, bw.y, bw.z, bw.w};
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_t<ACT>(acc[4 * g + j] + __builtin_bit_cast(float, bu[j]), p.slope);
+        if constexpr (HAS_RES) {
+            const unsigned e1 = opix * p.res1_ld + co, e2 = opix * p.res2_ld + co;
+            const v4u_t f1 = __builtin_amdgcn_raw_buffer_load_b128(R.r1, (ok && R.r1_f32) ? e1 * 4 : OOB, 0, 0);
+            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_bf16) ? e1 * 2 : OOB, 0, 0);
+            const v4u_t f2 = __builtin_amdgcn_raw_buffer_load_b128(R.r2, (ok && R.r2_f32) ? e2 * 4 : OOB, 0, 0);
+            const v2u_t h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_bf16) ? e2 * 2 : OOB, 0, 0);
+            const unsigned a1[4] = {f1.x, f1.y, f1.z, f1.w}, a2[4] = {f2.x, f2.y, f2.z, f2.w};
+            const unsigned b1[4] = {h1.x << 16, h1.x & 0xFFFF0000u, h1.y << 16, h1.y & 0xFFFF0000u};
+            const unsigned b2[4] = {h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[j] += (__builtin_bit_cast(float, a1[j]) + __builtin_bit_cast(float, b1[j])) +
+                        (__builtin_bit_cast(float, a2[j]) + __builtin_bit_cast(float, b2[j]));
+        }
+        const unsigned eo = opix * p.out_ld + co;
+        v4u_t of;
+        of.x = __builtin_bit_cast(unsigned, v[0]); of.y = __builtin_bit_cast(unsigned, v[1]);
+        of.z = __builtin_bit_cast(unsigned, v[2]); of.w = __builtin_bit_cast(unsigned, v[3]);
+        v2u_t ob;
+        ob.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        ob.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        __builtin_amdgcn_raw_buffer_store_b128(of, R.out, (ok && R.out_f32) ? eo * 4 : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(ob, R.out, (ok && !R.out_f32) ? eo * 2 : OOB, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void run_epilogue_direct(const ConvParams& p, const EpiRsrc& R, const rsrc_t& rbias, const f32x16& acc,
+                                                    unsigned opix, bool pix_ok, int cbase, int h) {
+#define DSVC_EPD_CASE(A)                                                                                         \
+    case A:                                                                                                      \
+        if (p.res1 || p.res2) epilogue_direct_tile<A, true>(p, R, rbias, acc, opix, pix_ok, cbase, h);            \
+        else epilogue_direct_tile<A, false>(p, R, rbias, acc, opix, pix_ok, cbase, h);                            \
+        break;
+    switch (p.act) {
+        DSVC_EPD_CASE(DSVC_ACT_RELU)
+        DSVC_EPD_CASE(DSVC_ACT_LRELU)
+        DSVC_EPD_CASE(DSVC_ACT_GELU)
+        DSVC_EPD_CASE(DSVC_ACT_SIGMOID)
+        DSVC_EPD_CASE(DSVC_ACT_HALF_TANH)
+        default:
+            if (p.res1 || p.res2) epilogue_direct_tile<DSVC_ACT_NONE, true>(p, R, rbias, acc, opix, pix_ok, cbase, h);
+            else epilogue_direct_tile<DSVC_ACT_NONE, false>(p, R, rbias, acc, opix, pix_ok, cbase, h);
+            break;
+    }
+#undef DSVC_EPD_CASE
+}
+
 template <typename CT> struct CTraits;
 template <> struct CTraits<float> { static constexpr int KCE = 16, EPV = 4; };
 template <> struct CTraits<__bf16> { static constexpr int KCE = 32, EPV = 8; };

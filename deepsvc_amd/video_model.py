@@ -6,6 +6,7 @@ return values, so `test_video.py:230-236,342,349` drives it unchanged.  Undernea
 of fused HIP launches over NHWC slices; see DESIGN.md section 3 for the dataflow and buffer plan.
 """
 import math
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 import torch.nn as nn
@@ -18,6 +19,7 @@ from .modules import (ME_Spynet, RefineNet, Reconstruction, FeatureExtraction, I
 from .ops import Act, to_act
 
 F32 = torch.float32
+_DECODE_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dsvc-resdec")
 
 
 class DeepSVC(nn.Module):
@@ -118,10 +120,27 @@ class DeepSVC(nn.Module):
         """video_model.py:153-167 -> (feature, recon, warped, predict), the three frames clamped to [0,1]."""
         ref = to_act(ref_frame)
         dev = ref.device
+        # The residual codec's decode chain (host range decoder + tiny scan kernels, 5 sync points) does not depend on
+        # the motion path until reconstruction: it runs on a worker thread / side stream so its idle gaps overlap the
+        # motion decode chain and the MC / feature-extraction kernels of the main stream.
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.setdefault("_side_streams", {}).setdefault(str(dev), torch.cuda.Stream(dev))
+        side.wait_stream(main)
+        res_done = torch.cuda.Event()
+
+        def decode_residual():
+            with torch.cuda.stream(side):
+                out = self.res_codec.run_decompress(res_out_enc["strings"], res_out_enc["shape"], dev)
+                res_done.record(side)
+            return out
+
+        res_future = _DECODE_POOL.submit(decode_residual)
         mv_coarse = self.mv_codec.run_decompress(mv_out_enc["strings"], mv_out_enc["shape"], dev, x_hat_dtype=F32)
         warped, warp_fea, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
         predict_fea = self.FeatureExtractor.run(predict)
-        res_coarse = self.res_codec.run_decompress(res_out_enc["strings"], res_out_enc["shape"], dev)
+        res_coarse = res_future.result()
+        main.wait_event(res_done)
+        res_coarse.buf.record_stream(main)
         feat, recon = self._reconstruct(ref, predict_fea, res_coarse, warp_fea)
         clamp = lambda a: ops.eltwise(N.EW_CLAMP01, a).nchw()
         # `feature` is only ever handed back to the next frame: return it zero-copy in its storage layout/dtype
