@@ -7,7 +7,8 @@
 //   * the MFMA A fragments are loaded STRAIGHT from HBM in operand layout -- lane (r,h) reads the 16 B holding channels
 //     [16ks+8h, +8) of pixel r -- with bounds-checked buffer loads (the ragged tail reads zeros); no LDS staging, no
 //     workgroup barriers; the next unit's fragments are in flight while the current unit's MFMAs and stores run;
-//   * the weights (<= 128x128) live in registers as B fragments for the whole launch;
+//   * the weights (<= 128x128, <= 40 KiB) are staged into LDS once per workgroup and read as B fragments per MFMA
+//     (keeping them in registers cost occupancy: 245 VGPRs at 96->96); output channels go in pairs of N-tiles;
 //   * the epilogue is the shared fused pass (bias, activation, gated residual, second residual, cast) through a
 //     wave-private LDS slab so that stores are 16-B vectors along the NHWC channel axis.
 #include "conv_common.h"
@@ -21,65 +22,60 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const ConvParams p, int nu
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPN = NT >= 2 ? 2 : 1;
     constexpr int EPLD = EPN * 32 + 4, GPP = EPN * 8;
+    constexpr int NCH = (KS + 1) / 2;                          // 64-B weight chunks (32 input channels each)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    float* slab = (float*)smem + wave * (32 * EPLD);
+    // LDS: weights [chunk][Np rows] at the 80-B pitch (conflict-free ds_read_b128) | one epilogue slab per wave
+    char* lds_w = smem;
+    float* slab = (float*)(smem + (size_t)NCH * p.Np * ROWB) + wave * (32 * EPLD);
+    {
+        const int nrows = NCH * p.Np, q = tid & 3;
+        for (int row = tid >> 2; row < nrows; row += 64)
+            *(uint4*)(lds_w + row * ROWB + q * 16) = *(const uint4*)((const char*)p.w + (size_t)row * 64 + q * 16);
+    }
+    __syncthreads();
     const EpiRsrc R = make_epi_rsrc(p);
     const rsrc_t rin = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
     const unsigned pitch = (unsigned)p.seg[0].ld * 2;
     const unsigned npix = (unsigned)p.Wo;                      // host presents the tensor as one row of B*H*W pixels
 
-    // weights -> registers (packed layout [chunk][tap=1][Np][64 B])
-    uint4 wreg[KS][NT];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int co = n * 32 + r;
-            wreg[ks][n] = co < p.Np ? *(const uint4*)((const char*)p.w + ((size_t)(ks >> 1) * p.Np + co) * 64 + (ks & 1) * 32 + h * 16)
-                                    : make_uint4(0, 0, 0, 0);
-        }
-
     const int nwaves = gridDim.x * 4;
     int unit = blockIdx.x * 4 + wave;
     auto load_a = [&](int u, uint4 (&a)[KS]) {
         const unsigned pix = (unsigned)u * 32 + r;
-        const unsigned base = pix < npix && u < nunits ? pix * pitch + h * 16 : OOB;
+        const bool ok = pix < npix && u < nunits;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = buf_load16(rin, base == OOB ? OOB : base + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) a[ks] = buf_load16(rin, ok ? pix * pitch + h * 16 + ks * 32 : OOB);
     };
+    const int b_lane = r * ROWB + h * 16;
     uint4 a_cur[KS], a_nxt[KS];
     load_a(unit, a_cur);
     for (; unit < nunits; unit += nwaves) {
         load_a(unit + nwaves, a_nxt);                          // prefetch (reads zeros past the end)
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[ks]),
-                                                                 __builtin_bit_cast(bf16x8, wreg[ks][n]), acc[n], 0, 0, 0);
-        // epilogue: <= 2 N-tiles per pass through the wave-private slab
-#define C1_PASS(N0)                                                                                                  \
+        // output channels in pairs of N-tiles: accumulate, then run the fused epilogue pass for that pair
+#define C1_PAIR(N0)                                                                                                  \
     if constexpr (N0 < NT) {                                                                                         \
-        _Pragma("unroll") for (int e = 0; e < EPN; ++e) {                                                            \
-            if (N0 + e < NT) {                                                                                       \
-                _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                       \
-                    slab[((i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[N0 + e < NT ? N0 + e : 0][i];  \
+        constexpr int NP = NT - N0 < EPN ? NT - N0 : EPN;                                                            \
+        f32x16 acc[EPN];                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < EPN; ++e)                                                              \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;                                          \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                            \
+            _Pragma("unroll") for (int e = 0; e < NP; ++e) {                                                         \
+                const uint4 bw = *(const uint4*)(lds_w + ((ks >> 1) * p.Np + (N0 + e) * 32) * ROWB + b_lane + (ks & 1) * 32); \
+                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[ks]),              \
+                                                                 __builtin_bit_cast(bf16x8, bw), acc[e], 0, 0, 0);   \
             }                                                                                                        \
-        }                                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < NP; ++e)                                                               \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                           \
+                slab[((i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[e][i];                              \
         __builtin_amdgcn_wave_barrier();                                                                             \
-        run_epilogue<GPP, EPLD, 32>(p, R, slab, lane, 0, 0, unit * 32, N0 * 32, (NT - N0 < EPN ? NT - N0 : EPN) * 32); \
+        run_epilogue<GPP, EPLD, 32>(p, R, slab, lane, 0, 0, unit * 32, N0 * 32, NP * 32);                            \
         __builtin_amdgcn_wave_barrier();                                                                             \
     }
-        C1_PASS(0) C1_PASS(2)
-#undef C1_PASS
+        C1_PAIR(0) C1_PAIR(2)
+#undef C1_PAIR
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
     }
@@ -88,7 +84,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const ConvParams p, int nu
 template <int KS, int NT>
 int launch_1x1(hipStream_t st, const ConvParams& p, int nunits) {
     constexpr int EPN = NT >= 2 ? 2 : 1;
-    const size_t lds = (size_t)4 * 32 * (EPN * 32 + 4) * sizeof(float);
+    const size_t lds = (size_t)((KS + 1) / 2) * p.Np * ROWB + (size_t)4 * 32 * (EPN * 32 + 4) * sizeof(float);
     int grid = (nunits + 3) / 4;
     if (grid > 256 * 4) grid = 256 * 4;                        // 4 workgroups (16 waves) per CU, grid-stride beyond
     hipLaunchKernelGGL((conv1x1_kernel<KS, NT>), dim3(grid), dim3(256), lds, st, p, nunits);

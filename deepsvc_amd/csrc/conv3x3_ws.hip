@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) conv3x3_ws_ker
         for (int j = 0; j < WS_PFV; ++j) {
             const int iy = oy0 - 1 + ppy[j], ix = ox0 - 1 + ppx[j];
             if constexpr (FAST) {   // bounds-checked buffer load: out-of-image pixels read as zeros, code stays straight-line
-                const bool inb = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const bool inb = c0 + q * EPV < sg.C && iy >= 0 && iy < H && ix >= 0 && ix < W;   // short chunk: zeros
                 pf[j] = buf_load16(make_rsrc(sg.ptr, sg.bytes), inb ? ((((unsigned)b * H + iy) * W + ix) * sg.ld + c0) * 2 + q * 16 : OOB);
             } else {
                 pf[j] = make_uint4(0, 0, 0, 0);
@@ -243,7 +243,7 @@ int dsvc_conv3x3_ws_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if (ntiles < 512) return 1;            // small images: the generic kernel's finer tiling fills the chip better
     bool fast = true;
-    for (int s = 0; s < p.nseg; ++s) fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == DSVC_BF16 && (p.seg[s].C % 32) == 0;
+    for (int s = 0; s < p.nseg; ++s) fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == DSVC_BF16 && (p.seg[s].C % 8) == 0;
     const int NT = d->Cout > 32 ? 2 : 1;
     // Direct stores from swapped-operand accumulators are implemented but measured SLOWER than the LDS-transposed epilogue
     // (285 vs 257 us on 64->64 @1088x1920: each store instruction touches 32 cache lines); opt-in for experiments only.

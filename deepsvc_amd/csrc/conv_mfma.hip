@@ -88,13 +88,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);      // out-of-image pixels read as zeros (bounds-checked loads)
             const unsigned pitch = (unsigned)sg.ld * sizeof(CT);
             const unsigned img = (unsigned)b * p.H * p.W * pitch + c0 * (unsigned)sizeof(CT) + q * 16;
+            const bool qvalid = c0 + q * EPV < sg.C;           // a short last chunk: the missing 16-B quarters read as zeros
             int py = py0, px = px0;
             for (int base = pix0; base < npatch; base += 64 * PB) {
                 uint4 v[PB];
 #pragma unroll
                 for (int j = 0; j < PB; ++j) {
                     const int iy = iy0 + py, ix = ix0 + px;
-                    const bool inb = base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    const bool inb = qvalid && base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                     v[j] = buf_load16(rs, inb ? img + ((unsigned)iy * p.W + ix) * pitch : OOB);
                     px += dpx; py += dpy;
                     if (px >= PW) { px -= PW; ++py; }
@@ -350,7 +351,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     }
     bool fast = true;
     for (int s = 0; s < d->nseg; ++s)
-        fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == d->compute && (p.seg[s].C % kce) == 0;
+        fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == d->compute && (p.seg[s].C % (kce / 4)) == 0;
 
     // ---- bf16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
     static const bool ws_enabled = getenv("DSVC_NO_WS") == nullptr;

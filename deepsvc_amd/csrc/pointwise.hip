@@ -144,6 +144,117 @@ __global__ void nhwc_to_nchw_kernel(const void* in, int in_ld, int in_dt, float*
 }
 
 struct Opnd { const void* p; int ld, dt; };
+constexpr int kSeBlocks = 512;   // partial sums per image
+// 8 consecutive channels as floats <-> one 16-B (bf16) or two 16-B (fp32) vectors
+__device__ __forceinline__ void load8(const void* p, int dt, int64_t off, float (&v)[8]) {
+    if (dt == DSVC_F32) {
+        const float4 a = *(const float4*)((const float*)p + off), b = *(const float4*)((const float*)p + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const uint4 t = *(const uint4*)((const unsigned short*)p + off);
+        const unsigned u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __builtin_bit_cast(float, u[j] << 16); v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u); }
+    }
+}
+__device__ __forceinline__ void store8(void* p, int dt, int64_t off, const float (&v)[8]) {
+    if (dt == DSVC_F32) {
+        *(float4*)((float*)p + off) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)p + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        unsigned u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = (unsigned)f32_to_bf16_bits(v[2 * j]) | ((unsigned)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+        *(uint4*)((unsigned short*)p + off) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+}
+inline bool vec8_ok(const void* p, int ld, int dt, int C) {
+    return p && (C % 8) == 0 && (ld % 8) == 0 && ((uintptr_t)p % 16) == 0 && (dt == DSVC_F32 || dt == DSVC_BF16);
+}
+
+// warp, 8 channels per thread, 16-B accesses (the 64-channel feature warp of InterLayerPrediction, modules.py:429)
+__global__ void warp8_kernel(const void* in, int in_ld, int in_dt, const float* flow, int flow_ld,
+                             void* out, int out_ld, int out_dt, int B, int H, int W, int C) {
+    const int cg = C / 8;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t pix = i / cg;
+        const int x = (int)(pix % W);
+        const int y = (int)((pix / W) % H);
+        const int64_t b = pix / ((int64_t)W * H);
+        const float2 f = *(const float2*)(flow + pix * flow_ld);
+        const float sx = fminf(fmaxf((float)x + f.x, 0.f), (float)(W - 1)), sy = fminf(fmaxf((float)y + f.y, 0.f), (float)(H - 1));
+        const float x0f = floorf(sx), y0f = floorf(sy);
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float ax = sx - x0f, ay = sy - y0f;
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
+        const int64_t base = b * H * W;
+        float a[8], bb[8], c[8], d[8], o[8];
+        load8(in, in_dt, (base + (int64_t)y0 * W + x0) * in_ld + g * 8, a);
+        load8(in, in_dt, (base + (int64_t)y0 * W + x1) * in_ld + g * 8, bb);
+        load8(in, in_dt, (base + (int64_t)y1 * W + x0) * in_ld + g * 8, c);
+        load8(in, in_dt, (base + (int64_t)y1 * W + x1) * in_ld + g * 8, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = w00 * a[j] + w01 * bb[j] + w10 * c[j] + w11 * d[j];
+        store8(out, out_dt, pix * out_ld + g * 8, o);
+    }
+}
+
+// elementwise family, 8 channels per thread (all operands 16-B aligned, C % 8 == 0)
+__global__ void eltwise8_kernel(int op, int64_t n_pix, int C, Opnd a, Opnd b, Opnd c, Opnd d, Opnd e,
+                                void* out, int out_ld, int out_dt) {
+    const int cg = C / 8;
+    const int64_t total = n_pix * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cg) * 8;
+        const int64_t pix = i / cg;
+        float va[8], vb[8], vc[8], vd[8], ve[8], o[8];
+        load8(a.p, a.dt, pix * a.ld + ch, va);
+        if (op == DSVC_EW_ADD || op == DSVC_EW_SUB || op == DSVC_EW_BLEND2 || op == DSVC_EW_BLEND3) load8(b.p, b.dt, pix * b.ld + ch, vb);
+        if (op == DSVC_EW_BLEND2 || op == DSVC_EW_BLEND3) load8(d.p, d.dt, pix * d.ld + ch, vd);
+        if (op == DSVC_EW_BLEND3) { load8(c.p, c.dt, pix * c.ld + ch, vc); load8(e.p, e.dt, pix * e.ld + ch, ve); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            switch (op) {
+                case DSVC_EW_ADD: o[j] = va[j] + vb[j]; break;
+                case DSVC_EW_SUB: o[j] = va[j] - vb[j]; break;
+                case DSVC_EW_BLEND2: o[j] = vd[j] * va[j] + (1.f - vd[j]) * vb[j]; break;
+                case DSVC_EW_BLEND3: o[j] = vd[j] * va[j] + ve[j] * vb[j] + (1.f - vd[j] - ve[j]) * vc[j]; break;
+                case DSVC_EW_CLAMP01: o[j] = fminf(fmaxf(va[j], 0.f), 1.f); break;
+                default: o[j] = va[j]; break;
+            }
+        }
+        store8(out, out_dt, pix * out_ld + ch, o);
+    }
+}
+
+// SE partial sums, 8 channels per thread: block j sums pixels j, j+kSeBlocks, ... (deterministic order)
+__global__ void se_partial8_kernel(const void* x, int ld, int dt, int64_t HW, int C, float* partial) {
+    extern __shared__ float red[];
+    const int b = blockIdx.y, j = blockIdx.x;
+    const int cg = C / 8;                           // thread -> (pixel lane, channel octet); 256 % cg == 0 for C in {32,64,128}
+    const int lanes = blockDim.x / cg;
+    const int g = threadIdx.x % cg, pl = threadIdx.x / cg;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t p = (int64_t)j * lanes + pl; p < HW; p += (int64_t)kSeBlocks * lanes) {
+        float v[8];
+        load8(x, dt, ((int64_t)b * HW + p) * ld + g * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(pl * cg + g) * 8 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float t = 0.f;
+        for (int k = 0; k < lanes; ++k) t += red[(k * cg + c / 8) * 8 + (c & 7)];
+        partial[((int64_t)b * kSeBlocks + j) * C + c] = t;
+    }
+}
+
 
 __global__ void eltwise_kernel(int op, int64_t n_pix, int C, Opnd a, Opnd b, Opnd c, Opnd d, Opnd e,
                                void* out, int out_ld, int out_dt) {
@@ -174,7 +285,6 @@ __global__ void eltwise_kernel(int op, int64_t n_pix, int C, Opnd a, Opnd b, Opn
 }
 
 // ---- SELayer (modules.py:217-230), deterministic two-stage mean ----------------------------------
-constexpr int kSeBlocks = 512;   // partial sums per image
 __global__ void se_partial_kernel(const void* x, int ld, int dt, int64_t HW, int C, float* partial) {
     // block (j, b): pixels j, j+kSeBlocks, ...; thread t handles channel t % C, pixel lane t / C
     extern __shared__ float red[];
@@ -260,7 +370,10 @@ extern "C" int dsvc_warp_bilinear_border(void* stream, const void* in, int32_t i
     DSVC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && in_ld >= C && out_ld >= C && flow_ld >= 2, "warp: bad shape");
     DSVC_REQUIRE(dt_ok(in_dtype) && dt_ok(out_dtype), "warp: bad dtype");
     hipStream_t st = (hipStream_t)stream;
-    if (C % 4 == 0) {
+    if (vec8_ok(in, in_ld, in_dtype, C) && vec8_ok(out, out_ld, out_dtype, C) && flow_ld % 2 == 0 && ((uintptr_t)flow % 8) == 0) {
+        const int64_t n = (int64_t)B * H * W * (C / 8);
+        hipLaunchKernelGGL(warp8_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+    } else if (C % 4 == 0) {
         const int64_t n = (int64_t)B * H * W * (C / 4);
         hipLaunchKernelGGL(warp_kernel<4>, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
     } else {
@@ -328,8 +441,13 @@ extern "C" int dsvc_eltwise(void* stream, int32_t op, int64_t n_pix, int32_t C, 
     DSVC_REQUIRE(!need_b || (b && b->ptr), "eltwise: operand b missing");
     DSVC_REQUIRE(!(op == DSVC_EW_BLEND2 || op == DSVC_EW_BLEND3) || (d && d->ptr), "eltwise: operand d missing");
     DSVC_REQUIRE(op != DSVC_EW_BLEND3 || (c && c->ptr && e && e->ptr), "eltwise: operands c/e missing");
-    hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n_pix * C)), dim3(kThreads), 0, (hipStream_t)stream, op, n_pix, C,
-                       mk(a), mk(b), mk(c), mk(d), mk(e), out, out_ld, out_dtype);
+    auto okv = [&](const dsvc_operand* o) { return !o || !o->ptr || vec8_ok(o->ptr, o->ld, o->dtype, C); };
+    if (vec8_ok(out, out_ld, out_dtype, C) && okv(a) && okv(b) && okv(c) && okv(d) && okv(e))
+        hipLaunchKernelGGL(eltwise8_kernel, dim3(grid_for(n_pix * (C / 8))), dim3(kThreads), 0, (hipStream_t)stream, op, n_pix, C,
+                           mk(a), mk(b), mk(c), mk(d), mk(e), out, out_ld, out_dtype);
+    else
+        hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n_pix * C)), dim3(kThreads), 0, (hipStream_t)stream, op, n_pix, C,
+                           mk(a), mk(b), mk(c), mk(d), mk(e), out, out_ld, out_dtype);
     DSVC_CHECK_LAUNCH("eltwise_kernel");
     return DSVC_OK;
 }
@@ -342,7 +460,10 @@ extern "C" int dsvc_se_gate(void* stream, const void* x, int32_t ld, int32_t dty
     DSVC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C <= 256 && 256 % C == 0 && hidden > 0 && ld >= C, "se_gate: C=%d must divide 256", C);
     hipStream_t st = (hipStream_t)stream;
     const int64_t HW = (int64_t)H * W;
-    hipLaunchKernelGGL(se_partial_kernel, dim3(kSeBlocks, B), dim3(256), 256 * sizeof(float), st, x, ld, dtype, HW, C, partial);
+    if (vec8_ok(x, ld, dtype, C) && 256 % (C / 8) == 0)
+        hipLaunchKernelGGL(se_partial8_kernel, dim3(kSeBlocks, B), dim3(256), 256 * 8 * sizeof(float), st, x, ld, dtype, HW, C, partial);
+    else
+        hipLaunchKernelGGL(se_partial_kernel, dim3(kSeBlocks, B), dim3(256), 256 * sizeof(float), st, x, ld, dtype, HW, C, partial);
     DSVC_CHECK_LAUNCH("se_partial_kernel");
     hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (C + hidden) * sizeof(float), st, partial, HW, C, hidden, w1, w2, gate);
     DSVC_CHECK_LAUNCH("se_gate_kernel");

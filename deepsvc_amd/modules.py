@@ -33,19 +33,56 @@ def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
 class Conv2d(nn.Conv2d):
     """nn.Conv2d parameters (same keys) executed by the fused MFMA conv kernel."""
 
-    def _packed(self, seg_channels, device):
-        key = (tuple(seg_channels), ops.RT.compute, str(device), self.weight._version,
-               -1 if self.bias is None else self.bias._version, self.weight.data_ptr())
+    def _packed(self, seg_channels, device, phys_channels=None):
+        key = (tuple(seg_channels), None if phys_channels is None else tuple(phys_channels), ops.RT.compute, str(device),
+               self.weight._version, -1 if self.bias is None else self.bias._version, self.weight.data_ptr())
         cache = self.__dict__.setdefault("_pack_cache", {})
         if key not in cache:
             cache.clear()
             cache[key] = ops.PackedConv(self.weight, self.bias, seg_channels, self.stride[0], self.padding[0],
-                                        ops.RT.compute, device)
+                                        ops.RT.compute, device, phys_channels)
         return cache[key]
 
+    def _pack_small_runs(self, inputs):
+        """bf16 mode: maximal runs of small fp32 inputs (frames, flows: 2-3 channels each) are merged into one bf16
+        buffer padded with zero channels to a multiple of 8, so the conv's fast 16-byte staging path applies.
+        Returns (physical inputs, logical channel split, physical channel split)."""
+        small = lambda a: a.dtype == torch.float32 and a.C < 32 and (a.C % 8 != 0)
+        phys, logical, physical, run = [], [], [], []
+
+        def flush():
+            if not run:
+                return
+            lc = sum(a.C for a in run)
+            pc = -(-lc // 8) * 8
+            x0 = run[0]
+            cache = self.__dict__.setdefault("_small_cache", {})
+            key = (len(phys), x0.B, x0.H, x0.W, pc, str(x0.device))
+            if key not in cache:          # zero-initialised once: the padding channels are never written afterwards
+                cache[key] = Act(torch.zeros((x0.B, x0.H, x0.W, pc), dtype=torch.bfloat16, device=x0.device))
+            phys.append(ops.pack_small_inputs(run, cache[key]))
+            logical.append(lc)
+            physical.append(pc)
+            run.clear()
+
+        for a in inputs:
+            if small(a):
+                run.append(a)
+            else:
+                flush()
+                phys.append(a)
+                logical.append(a.C)
+                physical.append(a.C)
+        flush()
+        return phys, logical, physical
+
     def run(self, inputs, out=None, **epilogue):
-        inputs = inputs if isinstance(inputs, (list, tuple)) else [inputs]
-        return ops.conv2d(self._packed([a.C for a in inputs], inputs[0].device), list(inputs), out, **epilogue)
+        inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        if ops.RT.compute == N.BF16 and any(a.dtype == torch.float32 and a.C % 8 != 0 and a.C < 32 for a in inputs):
+            phys, logical, physical = self._pack_small_runs(inputs)
+            if len(phys) <= 3:
+                return ops.conv2d(self._packed(logical, phys[0].device, physical), phys, out, **epilogue)
+        return ops.conv2d(self._packed([a.C for a in inputs], inputs[0].device), inputs, out, **epilogue)
 
     def forward(self, x):
         return self.run(to_act(x)).nchw()

@@ -126,10 +126,23 @@ def to_act(x, dtype=None):
 class PackedConv:
     """Device-resident packed weights (+ fp32 bias) of one conv for one (segments, compute type)."""
 
-    def __init__(self, w_oihw, bias, seg_channels, stride, pad, compute, device):
+    def __init__(self, w_oihw, bias, seg_channels, stride, pad, compute, device, phys_channels=None):
+        """seg_channels: how the weight's input channels split over the input segments (torch.cat order);
+        phys_channels: channels each segment physically provides (>= logical; the extra ones are zero padding of a
+        packed buffer) -- the weight gets zero columns there."""
         w = w_oihw.detach().to("cpu", torch.float32).contiguous()
         self.Cout, cin, self.kh, self.kw = w.shape
         assert sum(seg_channels) == cin, f"segments {seg_channels} do not add up to Cin={cin}"
+        if phys_channels is not None and tuple(phys_channels) != tuple(seg_channels):
+            parts, c = [], 0
+            for lc, pc in zip(seg_channels, phys_channels):
+                assert pc >= lc
+                parts.append(w[:, c:c + lc])
+                if pc > lc:
+                    parts.append(torch.zeros((self.Cout, pc - lc, self.kh, self.kw), dtype=torch.float32))
+                c += lc
+            w = torch.cat(parts, 1).contiguous()
+            seg_channels = phys_channels
         self.segC = tuple(int(c) for c in seg_channels)
         self.stride, self.pad, self.compute = stride, pad, compute
         segs = (ctypes.c_int32 * len(self.segC))(*self.segC)
@@ -335,6 +348,15 @@ class CdfTables:
         self.lut = np.empty((self.cdf.shape[0], 256), dtype=np.uint16)          # decode accelerator, owned here
         N.check(N.lib().dsvc_cdf_build_lut(byref(self.c), self.lut.ctypes.data), "cdf_build_lut")
         self.c.lut = self.lut.ctypes.data
+
+
+def pack_small_inputs(acts, buf):
+    """Copy (and cast) a run of small activations into consecutive channels of the zero-padded packed buffer `buf`."""
+    c = 0
+    for a in acts:
+        eltwise(N.EW_COPY, a, out=Act(buf.buf, buf.c0 + c, a.C))
+        c += a.C
+    return buf
 
 
 def pmf_to_quantized_cdf(pmf, precision=16):

@@ -213,6 +213,16 @@ def test_pointwise_and_reductions():
     report_close("blend2", ops.eltwise(N.EW_BLEND2, A, B, d=Wt).nchw().cpu(), w * a + (1 - w) * b, 1e-6, 1e-6)
     report_close("blend3", ops.eltwise(N.EW_BLEND3, A, B, C, Wt, V).nchw().cpu(), w * a + v * b + (1 - w - v) * c, 1e-6, 1e-6)
     report_close("clamp", ops.eltwise(N.EW_CLAMP01, A).nchw().cpu(), a.clamp(0, 1), 0, 0)
+    # 8-channel vector path (C % 8 == 0), mixed fp32 / bf16 operands
+    a, b, c = (torch.randn(2, 16, 9, 10) for _ in range(3))
+    w, v = torch.rand(2, 16, 9, 10), torch.rand(2, 16, 9, 10)
+    bf = torch.bfloat16
+    A, B, C, Wt, V = _act(a, bf), _act(b), _act(c, bf), _act(w), _act(v, bf)
+    ab, cb, vb = a.to(bf).float(), c.to(bf).float(), v.to(bf).float()
+    report_close("sub8", ops.eltwise(N.EW_SUB, A, B, out_dtype=torch.float32).nchw().cpu(), ab - b, 1e-6, 1e-6)
+    report_close("blend3_8", ops.eltwise(N.EW_BLEND3, A, B, C, Wt, V, out_dtype=torch.float32).nchw().cpu(),
+                 w * ab + vb * b + (1 - w - vb) * cb, 1e-5, 1e-5)
+    report_close("copy8", ops.eltwise(N.EW_COPY, B, out_dtype=bf).nchw().cpu(), b.to(bf).float(), 0, 0)
     x = torch.rand(2, 5, 33, 17) + 0.01
     y = torch.rand(2, 5, 33, 17)
     X, Y = _act(x), _act(y)
