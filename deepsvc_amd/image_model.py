@@ -27,16 +27,78 @@ F32 = torch.float32
 _CODER_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="dsvc-rans")   # ctypes calls release the GIL
 
 
-class PendingStrings:
-    """Range coding of one codec's symbols running on a worker thread (it first waits for the async device->host
-    copy of the symbol planes); `.result()` joins and returns the reference-style {"strings", "shape"} dict."""
+class PendingStrings(dict):
+    """The reference-style {"strings": [[y], [z...]], "shape": (h, w)} dict of one codec, whose range coding is still
+    running on a worker thread (behind the async device->host copy of the symbol planes).  Any access joins first, so
+    callers see a plain dict -- but a caller that does not look inside (DeepSVC.decompress hands the residual
+    encoding straight to its decode thread) lets the coding overlap with whatever it does next."""
 
     def __init__(self, future):
+        super().__init__()
         self._future = future
 
-    def result(self):
-        return self._future.result()
+    def _join(self):
+        if self._future is not None:
+            fut, self._future = self._future, None
+            super().update(fut.result())
+        return self
 
+    def result(self):
+        return self._join()
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self._join(), k)
+
+    def __contains__(self, k):
+        return dict.__contains__(self._join(), k)
+
+    def __iter__(self):
+        return dict.__iter__(self._join())
+
+    def __len__(self):
+        return dict.__len__(self._join())
+
+    def keys(self):
+        return dict.keys(self._join())
+
+    def values(self):
+        return dict.values(self._join())
+
+    def items(self):
+        return dict.items(self._join())
+
+    def get(self, k, default=None):
+        return dict.get(self._join(), k, default)
+
+    def __repr__(self):
+        return dict.__repr__(self._join())
+
+    def __eq__(self, other):
+        return dict.__eq__(self._join(), other)
+
+    __hash__ = None
+
+
+class _ScanPlan:
+    """Static device/pinned buffers of one codec at one latent shape: graph-captured scan segments address them."""
+
+    def __init__(self, codec, B, h, w, device):
+        Nc, d = codec.N, codec.slice_depth
+        self.device, self.epoch, self.graphs = device, -1, {}
+        act = lambda H, W, C: ops.new_act(B, H, W, C, F32, device)
+        self.y, self.y_hat, self.means, self.scales = act(h, w, Nc), act(h, w, Nc), act(h, w, Nc), act(h, w, Nc)
+        self.z_hat = act(h // 4, w // 4, Nc)
+        self.mus = [act(h, w, d) for _ in range(codec.num_slices)]
+        self.nz, self.ny, self.ns = B * Nc * (h // 4) * (w // 4), B * Nc * h * w, B * d * h * w
+        k = codec.max_support_slices
+        self.groups = [[i] for i in range(min(k, codec.num_slices))] + \
+                      ([list(range(k, codec.num_slices))] if codec.num_slices > k else [])
+        gmax = max(len(g) for g in self.groups)
+        i32 = lambda n, **kw: torch.empty(n, dtype=torch.int32, **kw)
+        self.staging = i32(self.nz + 2 * self.ny, device=device)      # encoder: [z symbols | y symbols | y indexes]
+        self.z_sym, self.z_sym_host = i32(self.nz, device=device), i32(self.nz, pin_memory=True)
+        self.idx_dev, self.sym_dev = i32(gmax * self.ns, device=device), i32(gmax * self.ns, device=device)
+        self.idx_host, self.sym_host = i32(gmax * self.ns, pin_memory=True), i32(gmax * self.ns, pin_memory=True)
 
 
 def conv3x3(cin, cout, stride=1):
@@ -112,12 +174,12 @@ class ChannelSplitICIP2020ResB(nn.Module):
     # ------------------------------------------------------------------------------------------
     # transforms on slices
     # ------------------------------------------------------------------------------------------
-    def _g_a(self, segments):
+    def _g_a(self, segments, out=None):
         x = segments
         last = len(self.g_a) - 1
         for i, m in enumerate(self.g_a):
             if isinstance(m, Conv2d):
-                x = m.run(x, out_dtype=F32 if i == last else None)   # the latent y stays fp32
+                x = m.run(x, out if i == last else None, out_dtype=F32 if i == last else None)   # the latent y stays fp32
             else:
                 x = m.run(x)
         return x
@@ -139,18 +201,18 @@ class ChannelSplitICIP2020ResB(nn.Module):
         return self.h_a[6].run(x, out_dtype=F32)
 
     @staticmethod
-    def _h_s(net, z_hat):
+    def _h_s(net, z_hat, out=None):
         x = net[0].run(z_hat, act=N.ACT_GELU, out_dtype=F32)
         x = net[2].run(x, act=N.ACT_GELU, out_dtype=F32)
         x = net[4].run(x, act=N.ACT_GELU, out_dtype=F32)
-        return net[6].run(x, out_dtype=F32)
+        return net[6].run(x, out, out_dtype=F32)
 
     def _support(self, latent, y_hat, i):
         k = min(i, self.max_support_slices)
         return [latent] if k == 0 else [latent, y_hat.ch(0, k * self.slice_depth)]
 
-    def _slice_params(self, i, means, scales, y_hat):
-        mu = _run_gelu_stack(self.cc_mean_transforms[i], self._support(means, y_hat, i))
+    def _slice_params(self, i, means, scales, y_hat, mu_out=None):
+        mu = _run_gelu_stack(self.cc_mean_transforms[i], self._support(means, y_hat, i), out=mu_out)
         sc = _run_gelu_stack(self.cc_scale_transforms[i], self._support(scales, y_hat, i))
         return mu, sc
 
@@ -188,34 +250,113 @@ class ChannelSplitICIP2020ResB(nn.Module):
             self._lrp(i, means, y_hat)
         return self._g_s(y_hat, x_hat_out, x_hat_dtype), y_lik, z_lik
 
-    def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None, defer=False):
-        """-> ({"strings", "shape"} or PendingStrings when defer=True, x_hat Act or None)."""
+    # ------------------------------------------------------------------------------------------
+    # scan plans: static workspace + HIP graphs of the launch-bound scan segments
+    # ------------------------------------------------------------------------------------------
+    def _plan(self, B, h, w, device):
+        key = (B, h, w, str(device), ops.RT.mode)
+        plans = self.__dict__.setdefault("_plans", {})
+        plan = plans.get(key)
+        if plan is None or plan.epoch != ops.PACK_EPOCH[0]:
+            if plan is None:
+                plan = plans[key] = _ScanPlan(self, B, h, w, device)
+            plan.graphs.clear()                  # weights were repacked since capture: the graphs hold stale pointers
+            plan.epoch = ops.PACK_EPOCH[0]
+        return plan
+
+    def _step(self, plan, key, fn):
+        """Run one scan segment: replay its HIP graph when one has been captured for the current weights, else eagerly.
+        A segment is a fixed sequence of ~20-90 tiny launches on static buffers with no host interaction -- exactly what
+        a graph is for: the CPU cost per segment drops from ~30 us per launch to one graph launch."""
+        g = plan.graphs.get(key) if ops.USE_GRAPHS[0] and plan.epoch == ops.PACK_EPOCH[0] else None
+        if g is not None:
+            g.replay()
+        else:
+            fn()
+
+    def capture_scan_graphs(self, B, h, w, device):
+        """Capture the scan segments of this codec at latent shape (h, w).  Must be called from a quiescent point (no
+        other thread issuing HIP work): DeepSVC does so at the entry of compress()/decompress() once the weight-packing
+        epoch has been stable for a whole call.  Returns True when the graphs are in place."""
+        if not ops.USE_GRAPHS[0]:
+            return False
+        ws = self._plan(B, h, w, device)
+        steps = self._segments(ws)
+        if all(k in ws.graphs for k in steps):
+            return True
+        for f in self.__dict__.get("_pending_futures", []):
+            f.result()
+        self.__dict__["_pending_futures"] = []
+        for t in (ws.z_sym, ws.sym_dev, ws.idx_dev, ws.staging):
+            t.zero_()
+        ws.y.buf.zero_()
+        epoch = ops.PACK_EPOCH[0]
+        for fn in steps.values():                 # eager warm-up on dummy data: packs weights, sets kernel attributes
+            fn()
+        torch.cuda.synchronize(device)
+        if ops.PACK_EPOCH[0] != epoch:            # something was packed just now: pointers may move again, retry later
+            self._plan(B, h, w, device)
+            return False
+        for key, fn in steps.items():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()                              # recorded, not executed
+            ws.graphs[key] = g
+        torch.cuda.synchronize(device)
+        return True
+
+    def _segments(self, ws):
+        """key -> closure of every capturable scan segment on workspace `ws` (encoder scan, decoder levels)."""
+        eb, device, groups = self.entropy_bottleneck, ws.device, ws.groups
+
+        def dec_first():
+            ops.eb_dequantize(ws.z_sym, eb.device_params(device), ws.z_hat)
+            self._h_s(self.h_scale_s, ws.z_hat, ws.scales)
+            self._h_s(self.h_mean_s, ws.z_hat, ws.means)
+            self._dec_nets(ws, groups[0])
+
+        def dec_level(group, nxt):
+            def level():
+                self._dec_finish(ws, group)
+                if nxt is not None:
+                    self._dec_nets(ws, nxt)
+            return level
+
+        steps = {"enc": lambda: self._enc_scan(ws), "dec0": dec_first}
+        for k, group in enumerate(groups):
+            steps[f"dec{k + 1}"] = dec_level(group, groups[k + 1] if k + 1 < len(groups) else None)
+        return steps
+
+    def _enc_scan(self, ws):
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck
-        y = self._g_a(segments)
-        z = self._h_a(y)
-        dev = y.device
-        z_hat = ops.new_act(z.B, z.H, z.W, z.C, F32, dev)
-        nz, ny = z.B * z.C * z.H * z.W, y.B * y.C * y.H * y.W
-        d = self.slice_depth
-        ns = y.B * d * y.H * y.W
-        staging = torch.empty(nz + 2 * ny, dtype=torch.int32, device=dev)   # [z symbols | y symbols | y indexes]
-        eb.quantize(z, True, z_hat, sym_out=staging[:nz])
-        scales, means = self._hyper(z_hat)
-        y_hat = ops.new_act(y.B, y.H, y.W, y.C, F32, dev)
-        table = gc.device_table(dev)
+        d, nz, ny, ns = self.slice_depth, ws.nz, ws.ny, ws.ns
+        z = self._h_a(ws.y)
+        eb.quantize(z, True, ws.z_hat, sym_out=ws.staging[:nz])
+        self._h_s(self.h_scale_s, ws.z_hat, ws.scales)
+        self._h_s(self.h_mean_s, ws.z_hat, ws.means)
+        table = gc.device_table(ws.device)
         for i in range(self.num_slices):
-            mu, sc = self._slice_params(i, means, scales, y_hat)
-            ops.gc_quantize(y.ch(i * d, d), mu, sc, table, True, True, y_hat.ch(i * d, d),
-                            sym_out=staging[nz + i * ns: nz + (i + 1) * ns],
-                            idx_out=staging[nz + ny + i * ns: nz + ny + (i + 1) * ns])
-            self._lrp(i, means, y_hat)
+            mu, sc = self._slice_params(i, ws.means, ws.scales, ws.y_hat, ws.mus[i])
+            ops.gc_quantize(ws.y.ch(i * d, d), mu, sc, table, True, True, ws.y_hat.ch(i * d, d),
+                            sym_out=ws.staging[nz + i * ns: nz + (i + 1) * ns],
+                            idx_out=ws.staging[nz + ny + i * ns: nz + ny + (i + 1) * ns])
+            self._lrp(i, ws.means, ws.y_hat)
+
+    def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None, defer=False):
+        """-> ({"strings", "shape"} dict (lazy PendingStrings when defer=True), x_hat Act or None)."""
+        gc, eb = self.gaussian_conditional, self.entropy_bottleneck
+        x0 = segments[0]
+        ws = self._plan(x0.B, x0.H // 16, x0.W // 16, x0.device)
+        self._g_a(segments, ws.y)
+        self._step(ws, "enc", lambda: self._enc_scan(ws))
+        nz, ny = ws.nz, ws.ny
         # Symbols leave the device through one async copy into pinned memory; the host range coder runs on a worker
         # thread behind the copy's event, so the caller can keep queuing GPU work (synthesis transform, MC, ...).
-        host = torch.empty(staging.numel(), dtype=torch.int32, pin_memory=True)
-        host.copy_(staging, non_blocking=True)
+        host = torch.empty(ws.staging.numel(), dtype=torch.int32, pin_memory=True)
+        host.copy_(ws.staging, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        zB, zC, zH, zW = z.B, z.C, z.H, z.W
+        zB, zC, zH, zW = ws.z_hat.B, ws.z_hat.C, ws.z_hat.H, ws.z_hat.W
 
         def encode():
             done.synchronize()
@@ -225,45 +366,48 @@ class ChannelSplitICIP2020ResB(nn.Module):
             enc.encode_with_indexes(packed[nz:nz + ny], packed[nz + ny:], gc.host_tables())
             return {"strings": [[enc.flush()], z_strings], "shape": (zH, zW)}
 
-        pending = PendingStrings(_CODER_POOL.submit(encode))
-        x_hat = self._g_s(y_hat, None, x_hat_dtype) if want_x_hat else None
+        future = _CODER_POOL.submit(encode)
+        self.__dict__.setdefault("_pending_futures", []).append(future)
+        del self.__dict__["_pending_futures"][:-4]      # keep only the most recent few (older ones have long finished)
+        pending = PendingStrings(future)
+        x_hat = self._g_s(ws.y_hat, None, x_hat_dtype) if want_x_hat else None
         return (pending if defer else pending.result()), x_hat
+
+    def _dec_nets(self, ws, group):
+        """parameter nets + index planes of one dependency level (slices of `group` share their support)."""
+        table, n = self.gaussian_conditional.device_table(ws.device), ws.ns
+        for j, i in enumerate(group):
+            mu, sc = self._slice_params(i, ws.means, ws.scales, ws.y_hat, ws.mus[i])
+            ops.gc_quantize(None, mu, sc, table, False, True, idx_out=ws.idx_dev[j * n:(j + 1) * n])
+
+    def _dec_finish(self, ws, group):
+        """symbols of one level -> y_hat slices (+ latent residual prediction)."""
+        d, n = self.slice_depth, ws.ns
+        for j, i in enumerate(group):
+            ops.gc_dequantize(ws.sym_dev[j * n:(j + 1) * n], ws.mus[i], ws.y_hat.ch(i * d, d))
+            self._lrp(i, ws.means, ws.y_hat)
 
     def run_decompress(self, strings, shape, device, x_hat_out=None, x_hat_dtype=None):
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck
         h4, w4 = int(shape[0]), int(shape[1])
         B = len(strings[1])
-        z_sym = torch.from_numpy(eb.decode_symbols(strings[1], h4, w4).reshape(-1)).to(device)
-        z_hat = ops.eb_dequantize(z_sym, eb.device_params(device), ops.new_act(B, h4, w4, self.N, F32, device))
-        scales, means = self._hyper(z_hat)
-        h, w, d = h4 * 4, w4 * 4, self.slice_depth
-        y_hat = ops.new_act(B, h, w, self.N, F32, device)
-        table, tables = gc.device_table(device), gc.host_tables()
-        dec = ops.RansDecoder(strings[0][0])
-        k = self.max_support_slices
-        groups = [[i] for i in range(min(k, self.num_slices))] + ([list(range(k, self.num_slices))] if self.num_slices > k else [])
-        n = B * d * h * w
-        gmax = max(len(g) for g in groups)
-        idx_dev = torch.empty(gmax * n, dtype=torch.int32, device=device)
-        sym_dev = torch.empty(gmax * n, dtype=torch.int32, device=device)
-        idx_host = torch.empty(gmax * n, dtype=torch.int32, pin_memory=True)     # pinned: async copies, no staging hop
-        sym_host = torch.empty(gmax * n, dtype=torch.int32, pin_memory=True)
+        ws = self._plan(B, h4 * 4, w4 * 4, device)
+        tables = gc.host_tables()
         stream = torch.cuda.current_stream(device)
-        for group in groups:
-            mus = []
-            for j, i in enumerate(group):        # parameter nets of a dependency level are queued together
-                mu, sc = self._slice_params(i, means, scales, y_hat)
-                ops.gc_quantize(None, mu, sc, table, False, True, idx_out=idx_dev[j * n:(j + 1) * n])
-                mus.append(mu)
+        ws.z_sym_host.numpy()[:] = eb.decode_symbols(strings[1], h4, w4).reshape(-1)
+        ws.z_sym.copy_(ws.z_sym_host, non_blocking=True)
+        dec = ops.RansDecoder(strings[0][0])
+        groups, n = ws.groups, ws.ns
+        steps = self._segments(ws)
+        self._step(ws, "dec0", steps["dec0"])
+        for k, group in enumerate(groups):
             m = len(group) * n
-            idx_host[:m].copy_(idx_dev[:m], non_blocking=True)
+            ws.idx_host[:m].copy_(ws.idx_dev[:m], non_blocking=True)
             stream.synchronize()                 # the one sync point of this level
-            dec.decode_stream(idx_host.numpy()[:m], tables, out=sym_host.numpy()[:m])
-            sym_dev[:m].copy_(sym_host[:m], non_blocking=True)
-            for j, i in enumerate(group):
-                ops.gc_dequantize(sym_dev[j * n:(j + 1) * n], mus[j], y_hat.ch(i * d, d))
-                self._lrp(i, means, y_hat)
-        return self._g_s(y_hat, x_hat_out, x_hat_dtype)
+            dec.decode_stream(ws.idx_host.numpy()[:m], tables, out=ws.sym_host.numpy()[:m])
+            ws.sym_dev[:m].copy_(ws.sym_host[:m], non_blocking=True)
+            self._step(ws, f"dec{k + 1}", steps[f"dec{k + 1}"])
+        return self._g_s(ws.y_hat, x_hat_out, x_hat_dtype)
 
     # ------------------------------------------------------------------------------------------
     # reference-style API (NCHW tensors)

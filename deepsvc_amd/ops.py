@@ -35,6 +35,11 @@ class Precision:
 
 
 RT = Precision()
+PACK_EPOCH = [0]          # bumped whenever a conv's weights are (re)packed: captured HIP graphs hold those pointers
+USE_GRAPHS = [True]       # entropy-scan segments are captured into HIP graphs and replayed (DSVC_NO_GRAPHS=1 disables)
+import os as _os
+if _os.environ.get("DSVC_NO_GRAPHS"):
+    USE_GRAPHS[0] = False
 
 
 def set_precision(mode):
@@ -154,6 +159,7 @@ class PackedConv:
                                          host.ctypes.data), "conv_pack_weights")
         self.weight = torch.from_numpy(host).to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+        PACK_EPOCH[0] += 1
 
 
 def deconv_as_conv_weights(w_iohw, bias):
