@@ -89,6 +89,7 @@ class _ScanPlan:
         self.y, self.y_hat, self.means, self.scales = act(h, w, Nc), act(h, w, Nc), act(h, w, Nc), act(h, w, Nc)
         self.z_hat = act(h // 4, w // 4, Nc)
         self.mus = [act(h, w, d) for _ in range(codec.num_slices)]
+        self.scs = [act(h, w, d) for _ in range(codec.num_slices)]
         self.nz, self.ny, self.ns = B * Nc * (h // 4) * (w // 4), B * Nc * h * w, B * d * h * w
         k = codec.max_support_slices
         self.groups = [[i] for i in range(min(k, codec.num_slices))] + \
@@ -126,7 +127,9 @@ def _run_gelu_stack(stack, segments, out=None, **last_epilogue):
     convs = [m for m in stack if isinstance(m, Conv2d)]
     x = segments
     for c in convs[:-1]:
-        x = c.run(x, act=N.ACT_GELU, out_dtype=F32)
+        # hidden activations in the storage type: in bf16 mode they would be rounded to bf16 when staged for the MFMA
+        # anyway (same single rounding), and bf16 storage puts the next layer on the conv's fast staging path
+        x = c.run(x, act=N.ACT_GELU, out_dtype=ops.RT.storage)
     return convs[-1].run(x, out, out_dtype=F32, **last_epilogue)
 
 
@@ -211,10 +214,19 @@ class ChannelSplitICIP2020ResB(nn.Module):
         k = min(i, self.max_support_slices)
         return [latent] if k == 0 else [latent, y_hat.ch(0, k * self.slice_depth)]
 
-    def _slice_params(self, i, means, scales, y_hat, mu_out=None):
-        mu = _run_gelu_stack(self.cc_mean_transforms[i], self._support(means, y_hat, i), out=mu_out)
-        sc = _run_gelu_stack(self.cc_scale_transforms[i], self._support(scales, y_hat, i))
-        return mu, sc
+    def _slice_params(self, i, means, scales, y_hat, mu_out=None, sc_out=None):
+        """mu_i, sigma_i: two independent 4-conv stacks -> forked onto two streams."""
+        return ops.run_parallel([
+            lambda: _run_gelu_stack(self.cc_mean_transforms[i], self._support(means, y_hat, i), out=mu_out),
+            lambda: _run_gelu_stack(self.cc_scale_transforms[i], self._support(scales, y_hat, i), out=sc_out)])
+
+    def _group_params(self, ws, group):
+        """mu_i, sigma_i for every slice of one dependency level: 2*len(group) independent 4-conv stacks, one flat fork."""
+        fns = []
+        for i in group:
+            fns.append(lambda i=i: _run_gelu_stack(self.cc_mean_transforms[i], self._support(ws.means, ws.y_hat, i), out=ws.mus[i]))
+            fns.append(lambda i=i: _run_gelu_stack(self.cc_scale_transforms[i], self._support(ws.scales, ws.y_hat, i), out=ws.scs[i]))
+        ops.run_parallel(fns)
 
     def _lrp(self, i, means, y_hat):
         """y_hat_i += 0.5*tanh(lrp_i(cat[mean_support, y_hat_i])) in place (image_model.py:185-188,244-247,292-295)."""
@@ -311,8 +323,8 @@ class ChannelSplitICIP2020ResB(nn.Module):
 
         def dec_first():
             ops.eb_dequantize(ws.z_sym, eb.device_params(device), ws.z_hat)
-            self._h_s(self.h_scale_s, ws.z_hat, ws.scales)
-            self._h_s(self.h_mean_s, ws.z_hat, ws.means)
+            ops.run_parallel([lambda: self._h_s(self.h_scale_s, ws.z_hat, ws.scales),
+                              lambda: self._h_s(self.h_mean_s, ws.z_hat, ws.means)])
             self._dec_nets(ws, groups[0])
 
         def dec_level(group, nxt):
@@ -332,15 +344,19 @@ class ChannelSplitICIP2020ResB(nn.Module):
         d, nz, ny, ns = self.slice_depth, ws.nz, ws.ny, ws.ns
         z = self._h_a(ws.y)
         eb.quantize(z, True, ws.z_hat, sym_out=ws.staging[:nz])
-        self._h_s(self.h_scale_s, ws.z_hat, ws.scales)
-        self._h_s(self.h_mean_s, ws.z_hat, ws.means)
+        ops.run_parallel([lambda: self._h_s(self.h_scale_s, ws.z_hat, ws.scales),
+                          lambda: self._h_s(self.h_mean_s, ws.z_hat, ws.means)])
         table = gc.device_table(ws.device)
-        for i in range(self.num_slices):
-            mu, sc = self._slice_params(i, ws.means, ws.scales, ws.y_hat, ws.mus[i])
-            ops.gc_quantize(ws.y.ch(i * d, d), mu, sc, table, True, True, ws.y_hat.ch(i * d, d),
+
+        def code_slice(i):
+            ops.gc_quantize(ws.y.ch(i * d, d), ws.mus[i], ws.scs[i], table, True, True, ws.y_hat.ch(i * d, d),
                             sym_out=ws.staging[nz + i * ns: nz + (i + 1) * ns],
                             idx_out=ws.staging[nz + ny + i * ns: nz + ny + (i + 1) * ns])
             self._lrp(i, ws.means, ws.y_hat)
+
+        for group in ws.groups:       # slices of one dependency level are independent: forked onto parallel streams
+            self._group_params(ws, group)
+            ops.run_parallel([(lambda i=i: code_slice(i)) for i in group])
 
     def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None, defer=False):
         """-> ({"strings", "shape"} dict (lazy PendingStrings when defer=True), x_hat Act or None)."""
@@ -376,16 +392,20 @@ class ChannelSplitICIP2020ResB(nn.Module):
     def _dec_nets(self, ws, group):
         """parameter nets + index planes of one dependency level (slices of `group` share their support)."""
         table, n = self.gaussian_conditional.device_table(ws.device), ws.ns
+
+        self._group_params(ws, group)
         for j, i in enumerate(group):
-            mu, sc = self._slice_params(i, ws.means, ws.scales, ws.y_hat, ws.mus[i])
-            ops.gc_quantize(None, mu, sc, table, False, True, idx_out=ws.idx_dev[j * n:(j + 1) * n])
+            ops.gc_quantize(None, ws.mus[i], ws.scs[i], table, False, True, idx_out=ws.idx_dev[j * n:(j + 1) * n])
 
     def _dec_finish(self, ws, group):
         """symbols of one level -> y_hat slices (+ latent residual prediction)."""
         d, n = self.slice_depth, ws.ns
-        for j, i in enumerate(group):
+
+        def one(j, i):
             ops.gc_dequantize(ws.sym_dev[j * n:(j + 1) * n], ws.mus[i], ws.y_hat.ch(i * d, d))
             self._lrp(i, ws.means, ws.y_hat)
+
+        ops.run_parallel([(lambda j=j, i=i: one(j, i)) for j, i in enumerate(group)])
 
     def run_decompress(self, strings, shape, device, x_hat_out=None, x_hat_dtype=None):
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck

@@ -54,6 +54,42 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+import threading as _threading
+
+_fork_pools = _threading.local()
+USE_FORKS = [_os.environ.get("DSVC_FORKS", "") != ""]   # opt-in: measured 17.15 vs 17.6 fps (event edges cost more than the overlap)
+
+
+def run_parallel(fns):
+    """Run independent launch sequences concurrently: branch 0 on the current stream, the others on side streams that
+    fork from it and join back.  Eagerly this overlaps tiny latency-bound kernels; under HIP-graph capture the forks
+    become parallel branches of the graph.  Each branch must allocate/free its temporaries itself (they live on its
+    stream) and write results into buffers that outlive the join."""
+    tl = _fork_pools.__dict__
+    if len(fns) == 1 or tl.get("depth", 0) > 0 or not USE_FORKS[0]:
+        # forks must stay FLAT: a fork inside a forked branch crashes hipStreamEndCapture on ROCm 7.0 (measured with
+        # tools/graph_fork_probe.py), so a nested call degrades to sequential issue on the branch's stream
+        return [fn() for fn in fns]
+    cur = torch.cuda.current_stream()
+    streams = tl.setdefault("streams", {}).setdefault((cur.device.index, cur.cuda_stream), [])
+    while len(streams) < len(fns) - 1:
+        streams.append(torch.cuda.Stream(cur.device))
+    out = [None] * len(fns)
+    tl["depth"] = 1
+    try:
+        for i, fn in enumerate(fns[1:]):
+            s = streams[i]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                out[i + 1] = fn()
+        out[0] = fns[0]()
+    finally:
+        tl["depth"] = 0
+        for s in streams[: len(fns) - 1]:
+            cur.wait_stream(s)
+    return out
+
+
 def _require_gpu(t):
     if not t.is_cuda:
         raise N.NativeError("deepsvc_amd ops run on the GPU only (got a CPU tensor); "
