@@ -1,0 +1,406 @@
+// conv3x3_pp.hip -- "ping-pong" bf16 3x3 stride-1 convolution, 64 input channels -> 32/64 output channels, bf16 NHWC in
+// and out, activation in {none, ReLU, LeakyReLU} on either side, optional bf16 residual(s): the ResBlock1 / in_conv
+// family that carries ~70 % of a 1080p P-frame's MACs (modules.py:200-204,307-311,322-340,382-418; census: 70
+// launches per frame at 1088x1920, tools/ws_census.py).
+//
+// Why a second kernel next to conv3x3_ws.hip: measured by skipping phases, that kernel's
+// time is the SUM of its MFMA phase (122 us), patch staging (60 us) and epilogue (67 us, 210 us with a residual):
+// its 8 waves move through the phases in lock step, so the matrix pipes idle whenever the waves stage or store.
+// Here a workgroup is TWO groups of 4 waves (one wave of each group on every SIMD), each group walking its own
+// 8x32-pixel tiles with its own halo-patch buffer, and group 1 runs ONE barrier phase behind group 0:
+//
+//     phase        1        2        3        4        1 ...
+//     group 0      M0       S1       M1       E+S0     M0          M<c> = 72 MFMAs on input chunk c (32 channels)
+//     group 1      E+S0     M0       S1       M1       E+S0        S<c> = write the prefetched chunk-c patch to LDS
+//                                                                  E    = fused epilogue of the finished tile
+//
+// so in every phase exactly one wave per SIMD feeds the matrix pipe while its partner does the vector / memory work.
+// The s_barrier is workgroup-wide; both groups execute the same number of barriers, group 1 simply starts with an
+// extra one and group 0 ends with one.
+//   * weights: all 2 chunks x 9 taps x Cout rows resident in LDS (80-B pitch), staged once per workgroup;
+//   * patch: 10x34 pixels x one 64-B chunk per group (80-B pitch: conflict-free ds_read_b128); the next chunk is
+//     prefetched into registers with bounds-checked buffer loads at the START of an M phase and written in the
+//     following S phase, so HBM/L2 latency rides under 72 MFMAs;
+//   * residual vectors of the tile are prefetched the same way at the start of M1;
+//   * epilogue WITHOUT LDS (a first version went through LDS slabs: its ds_write_b32 traffic, 64 B/clk, fought the
+//     other group's fragment reads and the phases stayed additive): the MFMA operand roles are swapped
+//     (A = weights, B = pixels), so D[channel][pixel] puts pixel lane&31 on the lane and 4 consecutive channels
+//     8*(reg>>2) + 4*(lane>>5) .. +3 in each register quad; one v_permlane32_swap per register exchanges quads
+//     between the two lane halves, after which every lane holds 8 CONSECUTIVE channels of its pixel; after bias,
+//     activation, residual and bf16 packing a v_permlane16_swap per packed dword regroups the lanes so that one
+//     16-B store instruction writes 64 contiguous bytes per pixel (16 cache lines per instruction instead of 32:
+//     store / residual-load issue was the longest part of the E phase).  Residuals are loaded in that same layout.  The bias is read from a
+//     small LDS table straight into the row-0 accumulators at the start of M0 and is the C operand of the first MFMAs.
+#include <cstdlib>
+#include "conv_common.h"
+
+using namespace dsvc_conv;
+
+namespace {
+
+constexpr int PP_TH = 8, PP_PW = 34, PP_NPATCH = (PP_TH + 2) * PP_PW;   // 340 patch pixels
+constexpr int PP_PFV = (PP_NPATCH * 4 + 255) / 256;                     // 6 prefetch vectors per thread
+
+__device__ __forceinline__ void buf_store16(rsrc_t r, unsigned off, uint4 v) {
+    v4u_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
+}
+
+// max(x, x*slope) for finite x in two VALU ops (fmaxf adds a canonicalising v_max per operand): med3(a, b, +inf) == max(a, b)
+__device__ __forceinline__ float lrelu_f(float x, float slope) {
+    return __builtin_amdgcn_fmed3f(x, x * slope, __builtin_inff());
+}
+// two floats -> one dword of packed bf16 (RNE), low half = a: exactly one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// 8 packed bf16 -> act(x) = max(x, x*slope) -> 8 packed bf16 (slope 0: ReLU; 0<slope<1: LeakyReLU)
+__device__ __forceinline__ uint4 act_bf16x8(uint4 val, float slope) {
+    unsigned u[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
+        u[k] = pk_bf16(lrelu_f(lo, slope), lrelu_f(hi, slope));
+    }
+    return make_uint4(u[0], u[1], u[2], u[3]);
+}
+
+template <int NT, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
+__global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
+                                                              float pre_slope) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTN = NT * 32, MTW = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PP_GROUP_PARITY
+    const int g = wave & 1, wg = wave >> 1, gtid = (wg << 6) | lane;   // group, wave in group, thread in group
+#else
+    const int g = wave >> 2, wg = wave & 3, gtid = tid & 255;      // group, wave in group, thread in group
+#endif
+    const int r = lane & 31, h = lane >> 5;
+    char* lds_w = smem;                                                       // [chunk 2][tap 9][NTN] rows of 80 B
+    char* lds_a = smem + 2 * 9 * NTN * ROWB + g * (PP_NPATCH * ROWB);          // this group's patch
+    float* lds_bias = (float*)(smem + 2 * 9 * NTN * ROWB + 2 * PP_NPATCH * ROWB);   // NTN floats
+    const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
+    const rsrc_t rr1 = make_rsrc(HAS_R1 ? p.res1 : p.out, HAS_R1 ? p.res1_bytes : p.out_bytes);
+    const rsrc_t rr2 = make_rsrc(HAS_R2 ? p.res2 : p.out, HAS_R2 ? p.res2_bytes : p.out_bytes);
+
+    // ---- weights: staged once (rows are [chunk][tap][Np == NTN] x 64 B in global memory) ----
+    {
+        const int nrows = 2 * 9 * NTN, q = tid & 3;
+        for (int base = tid >> 2; base < nrows; base += 128 * 6) {
+            uint4 v[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int row = base + 128 * j;
+                v[j] = make_uint4(0, 0, 0, 0);
+                if (row < nrows) v[j] = *(const uint4*)((const char*)p.w + (size_t)row * 64 + q * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (base + 128 * j < nrows) *(uint4*)(lds_w + (base + 128 * j) * ROWB + q * 16) = v[j];
+        }
+    }
+
+    if (tid < NTN) lds_bias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
+    const int H = p.H, W = p.W, tiles_x = p.tiles_x, tiles_y = p.tiles_y;
+    // Address arithmetic is kept off the vector ALU as far as possible (it runs beside the other group's MFMA phase):
+    // tile coordinates are wave-uniform and computed once per iteration; per-thread patch offsets are loop-invariant;
+    // products use the full-rate 24-bit multiplier (B*H*W < 2^24 is an eligibility condition).
+    struct TileOrg { int b, oy0, ox0; };
+    auto tile_origin = [&](int tile) -> TileOrg {
+        const int tx = tile % tiles_x;
+        const int rest = tile / tiles_x;
+        const int ty = rest % tiles_y;
+        return TileOrg{rest / tiles_y, ty * PP_TH, tx * 32};
+    };
+    // patch vector v = gtid + 256*j -> pixel v>>2 (row-major in the 10x34 patch), 16-B quarter v&3
+    const int q = gtid & 3;
+    int ppy[PP_PFV], ppx[PP_PFV], pp_pix[PP_PFV];
+#pragma unroll
+    for (int j = 0; j < PP_PFV; ++j) {
+        const int pix = (gtid >> 2) + 64 * j;
+        ppy[j] = pix / PP_PW; ppx[j] = pix - ppy[j] * PP_PW;
+        pp_pix[j] = ppy[j] * W + ppx[j];
+    }
+    const bool last_ok = (gtid >> 2) + 64 * (PP_PFV - 1) < PP_NPATCH;      // only the last vector can fall off the patch
+    auto load_chunk = [&](const TileOrg& t, int ch, uint4 (&pf)[PP_PFV]) {
+        const ConvSeg& sg = p.seg[(p.nseg > 1 && ch >= p.seg[1].chunk0) ? 1 : 0];
+        const rsrc_t rin = make_rsrc(sg.ptr, sg.bytes);
+        const unsigned ldb = (unsigned)sg.ld * 2, cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
+        const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;        // scalar; negative only where inb is false
+#pragma unroll
+        for (int j = 0; j < PP_PFV; ++j) {
+            const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
+            const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PP_PFV - 1 || last_ok);   // padding reads zeros
+            pf[j] = buf_load16(rin, inb ? __umul24((unsigned)(base_pix + pp_pix[j]), ldb) + cb : OOB);
+        }
+    };
+    auto store_chunk = [&](uint4 (&pf)[PP_PFV]) {
+#pragma unroll
+        for (int j = 0; j < PP_PFV; ++j) {
+            const int pix = (gtid >> 2) + 64 * j;
+            if (pix >= PP_NPATCH) continue;
+            *(uint4*)(lds_a + pix * ROWB + q * 16) = PRE ? act_bf16x8(pf[j], pre_slope) : pf[j];
+        }
+    };
+
+    int a_off[MTW], b_off[NT];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) a_off[m] = ((wg * MTW + m) * PP_PW + r) * ROWB + h * 32;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b_off[n] = (n * 32 + r) * ROWB + h * 32;
+
+    f32x16 acc[MTW][NT];
+    // 18 k-steps (9 taps x 2 halves of the 64-B chunk); the fragments of step s+1 are read before the MFMAs of step s
+    auto mfma_phase = [&](int ch, const bool FIRST) {   // FIRST (chunk 0, a literal at both call sites): start from the bias
+        const char* wt = lds_w + (size_t)ch * 9 * NTN * ROWB;
+        auto read_frags = [&](int s, uint4 (&af)[MTW], uint4 (&bf)[NT]) {
+            const int t = s >> 1, ks = s & 1;
+            const int tap_off = ((t / 3) * PP_PW + (t % 3)) * ROWB;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[n] = *(const uint4*)(wt + t * NTN * ROWB + b_off[n] + ks * 16);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) af[m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
+        };
+        if (FIRST) {   // chunk 0: row-0 accumulators start as the bias (reg i <-> channel (i&3) + 8*(i>>2) + 4*h);
+#pragma unroll               // row 1 takes them as the C operand of its first MFMA, issued before row 0's
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float4 bq = *(const float4*)(lds_bias + n * 32 + 8 * qd + 4 * h);
+                    acc[0][n][4 * qd] = bq.x; acc[0][n][4 * qd + 1] = bq.y; acc[0][n][4 * qd + 2] = bq.z; acc[0][n][4 * qd + 3] = bq.w;
+                }
+        }
+        uint4 af[3][MTW], bf[3][NT];                 // fragments are read TWO k-steps ahead: one step (4 MFMAs = 128 cycles)
+        read_frags(0, af[0], bf[0]);                // does not cover the ds_read latency while the other group also uses LDS
+        read_frags(1, af[1], bf[1]);
+        __builtin_amdgcn_s_setprio(3);              // the SIMD's issue arbiter otherwise favours the older group-0 waves:
+#pragma unroll                                      // their VALU-dense epilogue starved group 1's MFMAs (in-kernel stamps)
+        for (int s2 = 0; s2 < 18; ++s2) {
+            if (s2 + 2 < 18) read_frags(s2 + 2, af[(s2 + 2) % 3], bf[(s2 + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mm = 0; mm < MTW; ++mm)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int m = MTW - 1 - mm;      // row 1 first: its first MFMA reads row 0's still-untouched bias
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[s2 % 3][n]),   // D[channel][pixel]
+                                                                         __builtin_bit_cast(bf16x8, af[s2 % 3][m]),
+                                                                         (FIRST && s2 == 0) ? acc[0][n] : acc[m][n], 0, 0, 0);
+                }
+            // Empty asm that "updates" every accumulator: a data + chain dependency per k-step.  The MFMA intrinsics are
+            // pure, so instruction selection is otherwise free to sink a whole accumulation chain (18 MFMAs, all their
+            // fragments live -> spills) towards its only user, the epilogue; sched_barrier binds only the later scheduler.
+            if constexpr (NT == 2) asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            else asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // epilogue lane roles (after the half-swap): pixel r of the tile row, channels 16*P + 8*h .. +7 of the N-tile
+    // byte offset of this lane's first 8-channel vector (channels 8h..) of tile row m in an NHWC bf16 tensor with row
+    // pitch `ld`, or OOB; the other vectors of the pixel sit at constant byte offsets 32*P + 64*N from it (OOB + a
+    // small constant stays out of range, so masked lanes need no further care).  Cout == NT*32 on this path.
+    // MEMORY layout of the epilogue (after the second swap level, v_permlane16_swap on the packed dwords): lane l of
+    // vector `half` holds pixel (l&15) + 16*half of the tile row, channels 16*((l>>4)&1) + 8*(l>>5) .. +7 of the N-tile,
+    // i.e. 4 lanes cover 64 contiguous bytes of a pixel and one instruction touches 16 cache lines instead of 32.
+    auto row_off = [&](const TileOrg& t, int m, int ld, bool valid, int half) -> unsigned {
+        const int oy = t.oy0 + wg * MTW + m;                                          // scalar
+        const int px = (r & 15) + 16 * half;
+        const unsigned pix = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0) + px;
+        return (valid && oy < p.Ho && t.ox0 + px < p.Wo) ? __umul24(pix, (unsigned)ld * 2) + 32 * (r >> 4) + 16 * h : OOB;
+    };
+    uint4 res[MTW * NT * 2];
+    auto load_res = [&](const TileOrg& t, bool valid) {
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const unsigned base = row_off(t, m, p.res1_ld, valid, half);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) res[(m * NT + n) * 2 + half] = buf_load16(rr1, base + 64 * n);
+            }
+    };
+
+    // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD x = blockIdx % 8
+    // takes the x-th contiguous eighth of the tile raster (a band of tile rows) and its 32 workgroups x 2 groups sweep
+    // that band ~one tile row per iteration: the halo rows shared by vertically adjacent tiles are then re-read from
+    // the SAME L2 one iteration later (PMC: input fetch was 1.38x algorithmic with a chip-wide raster walk).
+    const int nband = (gridDim.x % 8 == 0) ? 8 : 1, per = (int)gridDim.x / nband;
+    const int band = (int)blockIdx.x % nband, band_tiles = (ntiles + nband - 1) / nband;
+    const int lt0 = ((int)blockIdx.x / nband) * 2 + g;
+    auto tile_raw = [&](int k) {           // tile index, or ntiles when this (group, k) has no tile
+        const int lt = lt0 + k * 2 * per;
+        const int t = band * band_tiles + lt;
+        return (lt < band_tiles && t < ntiles) ? t : ntiles;
+    };
+    auto tile_of = [&](int k) { return tile_raw(k); };
+    // All global loads are ISSUED in the S / E phases (which have slack) and consumed a full iteration (four phases,
+    // ~7 us) later: each input-chunk stream has its own register buffer (pf0: chunk 0 of tile k+2, pf1: chunk 1 of
+    // tile k+1) and the residual of tile k+1 is requested as soon as tile k's epilogue has consumed its registers.
+    // In-kernel stamps showed a load issued ONE M phase (~2 us) ahead still stalling its consumer, and an M phase with
+    // the prefetch address arithmetic in front of its MFMAs taking ~4000 cycles instead of ~2700.
+    uint4 pf0[PP_PFV], pf1[PP_PFV];
+    TileOrg cur = tile_origin(min(tile_of(0), ntiles - 1)), nxt = tile_origin(min(tile_of(1), ntiles - 1));
+    load_chunk(cur, 0, pf0);
+    store_chunk(pf0);
+    load_chunk(cur, 1, pf1);
+    load_chunk(nxt, 0, pf0);
+    if constexpr (HAS_R1) load_res(cur, tile_of(0) < ntiles);
+    lds_barrier();                       // weights, bias and both groups' first patches are in place
+    if (g) lds_barrier();                // group 1 runs one phase behind group 0
+
+    for (int k = 0; k < iters; ++k) {
+        const bool valid = tile_of(k) < ntiles;
+        // ---- M0 ----
+        mfma_phase(0, true);
+        lds_barrier();
+        // ---- S1 (+ prefetch: next tile's chunk 1) ----
+        store_chunk(pf1);
+        load_chunk(nxt, 1, pf1);
+        lds_barrier();
+        // ---- M1 ----
+        mfma_phase(1, false);
+        lds_barrier();
+        // ---- E + S0 (+ prefetch: chunk 0 of the tile after next, the next tile's residual) ----
+        {
+            unsigned o_out[MTW][2], o_r2[MTW][2];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    o_out[m][half] = row_off(cur, m, p.out_ld, valid, half);
+                    o_r2[m][half] = HAS_R2 ? row_off(cur, m, p.res2_ld, valid, half) : OOB;
+                }
+            // One 32x32 accumulator tile (tile row M, N-tile N) at a time, written out with static indices (a rolled loop
+            // would push acc[][] to scratch).  COMPUTE layout after the first swap level: lane (r, h) holds, for
+            // P = 0, 1, the 8 channels 16P + 8h .. +7 of pixel r (v0 / v1).  Residuals arrive in the memory layout
+            // and are brought to the compute layout by the same (involutive) 16-lane swap that the packed results
+            // take on their way out.
+#define SWAP32(X, Y, LO, HI)                                                                                        \
+    { const float xq = (X), yq = (Y);   /* scalars first: hipcc 7.2 mis-casts vector elements */                    \
+      const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false); \
+      const unsigned lo_ = sw.x, hi_ = sw.y; (LO) = __builtin_bit_cast(float, lo_); (HI) = __builtin_bit_cast(float, hi_); }
+#define SWAP16(X, Y, A, B)                                                                                          \
+    { const v2u_t sw = __builtin_amdgcn_permlane16_swap((X), (Y), false, false); (A) = sw.x; (B) = sw.y; }
+#define PP_TILE(M, N)                                                                                               \
+    if constexpr (N < NT) {                                                                                         \
+        float v0[8], v1[8];                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+            SWAP32(acc[M][N][j], acc[M][N][4 + j], v0[j], v0[4 + j])                                                \
+            SWAP32(acc[M][N][8 + j], acc[M][N][12 + j], v1[j], v1[4 + j])                                           \
+        }                                                                                                           \
+        if constexpr (ACT) {                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { v0[j] = lrelu_f(v0[j], act_slope); v1[j] = lrelu_f(v1[j], act_slope); } \
+        }                                                                                                           \
+        if constexpr (HAS_R1) {                                                                                     \
+            const uint4 ra = res[(M * NT + N) * 2], rb = res[(M * NT + N) * 2 + 1];                                 \
+            const unsigned ma[4] = {ra.x, ra.y, ra.z, ra.w}, mb[4] = {rb.x, rb.y, rb.z, rb.w};                      \
+            unsigned xa[4], xb[4];                                                                                  \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(ma[d], mb[d], xa[d], xb[d])                        \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+                v0[2 * j] += __builtin_bit_cast(float, xa[j] << 16); v0[2 * j + 1] += __builtin_bit_cast(float, xa[j] & 0xFFFF0000u); \
+                v1[2 * j] += __builtin_bit_cast(float, xb[j] << 16); v1[2 * j + 1] += __builtin_bit_cast(float, xb[j] & 0xFFFF0000u); \
+            }                                                                                                       \
+            if constexpr (HAS_R2) {                                                                                 \
+                const uint4 ca = buf_load16(rr2, o_r2[M][0] + 64 * N), cb = buf_load16(rr2, o_r2[M][1] + 64 * N);   \
+                const unsigned na[4] = {ca.x, ca.y, ca.z, ca.w}, nb[4] = {cb.x, cb.y, cb.z, cb.w};                  \
+                unsigned ya[4], yb[4];                                                                              \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(na[d], nb[d], ya[d], yb[d])                    \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+                    v0[2 * j] += __builtin_bit_cast(float, ya[j] << 16); v0[2 * j + 1] += __builtin_bit_cast(float, ya[j] & 0xFFFF0000u); \
+                    v1[2 * j] += __builtin_bit_cast(float, yb[j] << 16); v1[2 * j + 1] += __builtin_bit_cast(float, yb[j] & 0xFFFF0000u); \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        unsigned s0[4], s1[4];                                                                                      \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                               \
+            SWAP16(pk_bf16(v0[2 * d], v0[2 * d + 1]), pk_bf16(v1[2 * d], v1[2 * d + 1]), s0[d], s1[d])             \
+        buf_store16(rout, o_out[M][0] + 64 * N, make_uint4(s0[0], s0[1], s0[2], s0[3]));                            \
+        buf_store16(rout, o_out[M][1] + 64 * N, make_uint4(s1[0], s1[1], s1[2], s1[3]));                            \
+    }
+            PP_TILE(0, 0) PP_TILE(0, 1) PP_TILE(1, 0) PP_TILE(1, 1)
+#undef PP_TILE
+#undef SWAP16
+#undef SWAP32
+        }
+        store_chunk(pf0);
+        cur = nxt;
+        nxt = tile_origin(min(tile_of(k + 2), ntiles - 1));
+        load_chunk(nxt, 0, pf0);
+        if constexpr (HAS_R1) load_res(cur, tile_of(k + 1) < ntiles);
+        lds_barrier();
+    }
+    if (!g) lds_barrier();               // matches group 1's leading barrier
+}
+
+template <int NT, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
+int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, float pre_slope) {
+    const size_t lds = (size_t)2 * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)NT * 32 * sizeof(float);
+    static bool attr_set = false;
+    auto kern = conv3x3_pp_kernel<NT, PRE, ACT, HAS_R1, HAS_R2>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
+        attr_set = true;
+    }
+    int grid = (ntiles + 1) / 2;
+    if (grid > 256) grid = 256;                                  // one persistent workgroup per CU, two tiles in flight each
+    const int nband = grid % 8 == 0 ? 8 : 1, band_tiles = (ntiles + nband - 1) / nband;   // as in the kernel
+    const int iters = (band_tiles + 2 * (grid / nband) - 1) / (2 * (grid / nband));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, ntiles, iters, act_slope, pre_slope);
+    DSVC_CHECK_LAUNCH("conv3x3_pp_kernel");
+    return DSVC_OK;
+}
+
+template <int NT, bool PRE, bool ACT>
+int launch_pp_res(hipStream_t st, const ConvParams& p, int ntiles, float a, float b) {
+    if (p.res1 && p.res2) return launch_pp<NT, PRE, ACT, true, true>(st, p, ntiles, a, b);
+    if (p.res1) return launch_pp<NT, PRE, ACT, true, false>(st, p, ntiles, a, b);
+    return launch_pp<NT, PRE, ACT, false, false>(st, p, ntiles, a, b);
+}
+
+template <int NT>
+int launch_pp_act(hipStream_t st, const ConvParams& p, int ntiles, bool pre, bool act, float a, float b) {
+    if (pre) return act ? launch_pp_res<NT, true, true>(st, p, ntiles, a, b) : launch_pp_res<NT, true, false>(st, p, ntiles, a, b);
+    return act ? launch_pp_res<NT, false, true>(st, p, ntiles, a, b) : launch_pp_res<NT, false, false>(st, p, ntiles, a, b);
+}
+
+bool slope_of(int act, float slope, float* out) {
+    if (act == DSVC_ACT_NONE) { *out = 1.f; return true; }       // max(v, v*1) == v
+    if (act == DSVC_ACT_RELU) { *out = 0.f; return true; }
+    if (act == DSVC_ACT_LRELU && slope >= 0.f && slope <= 1.f) { *out = slope; return true; }
+    return false;
+}
+
+bool vec16_ok(const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (ld % 8) == 0; }
+
+}  // namespace
+
+// returns 1 when the shape is not covered (caller tries conv3x3_ws / the generic kernel), else DSVC_OK / error
+int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
+    if (d->compute != DSVC_BF16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
+    if (p_in.nchunks != 2 || p_in.nseg > 2 || (d->Cout != 32 && d->Cout != 64) || d->res1_scale) return 1;
+    if (d->out_dtype != DSVC_BF16 || !vec16_ok(d->out, d->out_ld)) return 1;
+    if (d->res1 && (d->res1_dtype != DSVC_BF16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
+    if (d->res2 && (!d->res1 || d->res2_dtype != DSVC_BF16 || !vec16_ok(d->res2, d->res2_ld))) return 1;
+    for (int s = 0; s < p_in.nseg; ++s) {                          // every 64-B chunk is a full, aligned 32-channel vector row
+        const ConvSeg& sg = p_in.seg[s];
+        if (sg.dtype != DSVC_BF16 || (sg.C % 32) != 0 || !vec16_ok(sg.ptr, sg.ld)) return 1;
+    }
+    float act_slope, pre_slope;
+    if (!slope_of(d->act, d->slope, &act_slope) || !slope_of(d->pre_act, d->slope, &pre_slope)) return 1;
+    ConvParams p = p_in;
+    p.tiles_x = (p.Wo + 31) / 32;
+    p.tiles_y = (p.Ho + PP_TH - 1) / PP_TH;
+    const int ntiles = p.B * p.tiles_x * p.tiles_y;
+    if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;   // pixel indices go through the 24-bit multiplier
+    if (ntiles < 1024) return 1;           // small images: the generic kernel's finer tiling fills the chip better
+    const bool pre = d->pre_act != DSVC_ACT_NONE, act = d->act != DSVC_ACT_NONE;
+    if (d->Cout == 64) return launch_pp_act<2>(st, p, ntiles, pre, act, act_slope, pre_slope);
+    return launch_pp_act<1>(st, p, ntiles, pre, act, act_slope, pre_slope);
+}

@@ -25,6 +25,7 @@
 
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 namespace {
 using namespace dsvc_conv;
@@ -357,6 +358,11 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     static const bool ws_enabled = getenv("DSVC_NO_WS") == nullptr;
     if (ws_enabled) {   // bf16 pointwise convs: streaming kernel, no LDS staging
         const int rc = dsvc_conv1x1_try((hipStream_t)stream, p, d);
+        if (rc != 1) return rc;
+    }
+    static const bool pp_enabled = getenv("DSVC_NO_PP") == nullptr;
+    if (ws_enabled && pp_enabled) {   // 64-channel bf16 ResBlock family: two phase-skewed wave groups per CU
+        const int rc = dsvc_conv3x3_pp_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;
     }
     if (ws_enabled) {

@@ -143,6 +143,51 @@ def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
     report_close("rs fused", fused, want2, 2e-2, 2e-2 * float(want2.abs().max()))
 
 
+@pytest.mark.parametrize("segs,cout,B,H,W,pre,act,nres", [
+    ((64,), 64, 1, 256, 1024, 0, 0, 0),      # exact tiles, plain
+    ((64,), 64, 1, 250, 1100, 2, 2, 1),      # ragged bottom/right tiles, LeakyReLU both sides, one residual
+    ((64,), 64, 1, 251, 1043, 1, 1, 2),      # odd sizes, ReLU both sides, two residuals
+    ((64,), 64, 1, 264, 1000, 0, 0, 1),      # ResBlock tail: residual only
+    ((32, 32), 64, 1, 250, 1090, 0, 2, 0),   # two 32-channel segments (virtual cat)
+    ((64,), 32, 1, 256, 1056, 0, 2, 1),      # 32 output channels
+    ((64,), 64, 2, 130, 1000, 2, 0, 1),      # batch of two
+])
+def test_conv3x3_pingpong_kernel(segs, cout, B, H, W, pre, act, nres):
+    """The 64-channel bf16 ResBlock family takes the two-group phase-skewed kernel (csrc/conv3x3_pp.hip): every
+    fused variant it accepts against torch on the same bf16-rounded operands, plus agreement with the
+    weight-stationary kernel it replaces (DSVC_NO_PP is read once per process, so that leg uses an fp32-output
+    launch, which the ping-pong kernel does not take)."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + H)
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        rs = [torch.randn(B, cout, H, W) for _ in range(nres)]
+        kw = dict(pre_act=pre, act=act, slope=0.05)
+        if nres >= 1:
+            kw["res1"] = _act(rs[0], bf)
+        if nres >= 2:
+            kw["res2"] = _act(rs[1], bf)
+        ins = [_act(x, bf) for x in xs]
+        got = m.run(ins if len(ins) > 1 else ins[0], out_dtype=bf, **kw).nchw().cpu()
+        other = m.run(ins if len(ins) > 1 else ins[0], out_dtype=torch.float32, **kw).nchw().cpu()   # WS / generic kernel
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    xb = torch.cat([x.to(bf).float() for x in xs], 1)
+    xin = _torch_act(xb, pre, 0.05).to(bf).float() if pre else xb
+    want = _torch_act(F.conv2d(xin, w, b, padding=1), act, 0.05)
+    for r in rs:
+        want = want + r.to(bf).float()
+    assert got.shape == want.shape
+    tol = 2e-2 * float(want.abs().max())
+    report_close("pp vs torch", got, want, 2e-2, tol)
+    report_close("pp vs ws", got, other, 1e-2, 1e-2 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
 def test_conv1x1_streaming_kernel(cin, cout):
     """Large bf16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,

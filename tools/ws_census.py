@@ -1,0 +1,36 @@
+"""Census of conv launch configurations in one P-frame (compress+decompress): which fused-epilogue variants occur on the
+large 3x3 convs.  python tools/ws_census.py"""
+import collections, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepsvc_amd import ops, synth, _native as N  # noqa: E402
+from deepsvc_amd.modules import pad  # noqa: E402
+
+ops.set_precision("bf16")
+dev = "cuda:0"
+model = synth.make_model("W0"); model.update(force=True); model = model.to(dev)
+frames = [pad(f.to(dev), 64) for f in synth.make_frames(1080, 1920, 3)]
+sms = [synth.make_sm_fea(1088, 1920, t).to(dev) for t in range(3)]
+mv, res = model.compress(frames[0], frames[1], sms[1], None)
+feat, ref, _, _ = model.decompress(frames[0], mv, res, sms[1], None)
+torch.cuda.synchronize()
+ops.USE_GRAPHS[0] = False
+cnt = collections.Counter()
+orig = ops.conv2d
+ACT = ["none", "relu", "lrelu", "gelu", "sigm", "htanh"]
+def dt(a): return "-" if a is None else str(a.dtype)[6:].replace("float32", "f32").replace("bfloat16", "bf16")
+def wrapped(pc, inputs, out=None, *, act=0, pre_act=0, slope=0.01, res1=None, gate=None, res2=None, shuffle=1, out_dtype=None):
+    o = orig(pc, inputs, out, act=act, pre_act=pre_act, slope=slope, res1=res1, gate=gate, res2=res2, shuffle=shuffle, out_dtype=out_dtype)
+    x = inputs[0]
+    cnt[(pc.kh, pc.stride, pc.segC, tuple(dt(a) for a in inputs), pc.Cout, x.H, x.W, "pre=" + ACT[pre_act], "act=" + ACT[act],
+         "r1=" + dt(res1), "gate" if gate is not None else "", "r2=" + dt(res2), "sh%d" % shuffle, "out=" + dt(o))] += 1
+    return o
+ops.conv2d = wrapped
+mv, res = model.compress(ref, frames[2], sms[2], feat)
+dict(mv); dict(res)
+model.decompress(ref, mv, res, sms[2], feat)
+torch.cuda.synchronize()
+for k, n in sorted(cnt.items(), key=lambda kv: -(kv[0][5] * kv[0][6] * sum(kv[0][2]) * kv[0][4] * kv[0][0] ** 2 // kv[0][1] ** 2) * kv[1]):
+    flop = 2.0 * k[5] * k[6] * sum(k[2]) * k[4] * k[0] ** 2 / k[1] ** 2 * n
+    if flop < 2e9: continue
+    print(f"{n:4d} {flop/1e9:8.1f} GF ", *k)
