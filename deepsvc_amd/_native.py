@@ -50,6 +50,7 @@ SIGNATURES = {
     "dsvc_last_error": (c_char_p, []),
     "dsvc_version": (c_int, []),
     "dsvc_device_count": (c_int, []),
+    "dsvc_set_option": (c_int, [c_char_p, c_int]),
     "dsvc_conv_packed_bytes": (c_int64, [c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32]),
     "dsvc_conv_pack_weights": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "dsvc_deconv5x5s2_to_conv3x3": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

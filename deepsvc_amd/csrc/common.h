@@ -27,6 +27,12 @@ void dsvc_set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
+// ---- kernel-selection switches of dsvc_conv2d (dsvc_set_option, host_misc.cpp) ------------------
+struct DsvcOptions {
+    int specialised, pp, ws, conv1x1, direct, direct_max_pix, ws_waves4, ws_direct_store;
+};
+extern DsvcOptions g_dsvc_opt;
+
 // ---- element access with runtime storage type ------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned int)b << 16);

@@ -247,10 +247,10 @@ int dsvc_conv3x3_ws_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     const int NT = d->Cout > 32 ? 2 : 1;
     // Direct stores from swapped-operand accumulators are implemented but measured SLOWER than the LDS-transposed epilogue
     // (285 vs 257 us on 64->64 @1088x1920: each store instruction touches 32 cache lines); opt-in for experiments only.
-    static const bool direct_enabled = getenv("DSVC_WS_DIRECT") != nullptr;
+    const bool direct_enabled = g_dsvc_opt.ws_direct_store != 0;
     const bool direct = direct_enabled && p.epi_vec && !p.res1_scale;
     // one wave per SIMD with a 4xNT register tile measured slower (371 vs 251 us): opt-in only
-    static const bool one_wave_per_simd = getenv("DSVC_WS_WAVES4") != nullptr;
+    const bool one_wave_per_simd = g_dsvc_opt.ws_waves4 != 0;
     if (direct) {
         if (fast) return NT == 2 ? launch_ws<2, true, true, 8>(st, p, ntiles) : launch_ws<1, true, true, 8>(st, p, ntiles);
         return NT == 2 ? launch_ws<2, false, true, 8>(st, p, ntiles) : launch_ws<1, false, true, 8>(st, p, ntiles);

@@ -26,6 +26,7 @@
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv3x3_direct_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 namespace {
 using namespace dsvc_conv;
@@ -355,19 +356,22 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
         fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == d->compute && (p.seg[s].C % (kce / 4)) == 0;
 
     // ---- bf16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
-    static const bool ws_enabled = getenv("DSVC_NO_WS") == nullptr;
-    if (ws_enabled) {   // bf16 pointwise convs: streaming kernel, no LDS staging
+    const DsvcOptions& opt = g_dsvc_opt;
+    if (opt.specialised && opt.direct) {    // small images (entropy-scan nets): barrier-free kernel, fragments straight from L2
+        const int rc = dsvc_conv3x3_direct_try((hipStream_t)stream, p, d);
+        if (rc != 1) return rc;             // 1 = not applicable, try the next kernel
+    }
+    if (opt.specialised && opt.conv1x1) {   // bf16 pointwise convs: streaming kernel, no LDS staging
         const int rc = dsvc_conv1x1_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;
     }
-    static const bool pp_enabled = getenv("DSVC_NO_PP") == nullptr;
-    if (ws_enabled && pp_enabled) {   // 64-channel bf16 ResBlock family: two phase-skewed wave groups per CU
+    if (opt.specialised && opt.pp) {        // 64-channel bf16 ResBlock family: two phase-skewed wave groups per CU
         const int rc = dsvc_conv3x3_pp_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;
     }
-    if (ws_enabled) {
+    if (opt.specialised && opt.ws) {        // other large bf16 3x3 convs with <= 64 input channels: LDS-resident weights
         const int rc = dsvc_conv3x3_ws_try((hipStream_t)stream, p, d);
-        if (rc != 1) return rc;   // 1 = not applicable, fall through to the generic kernel
+        if (rc != 1) return rc;
     }
     // ---- tile configuration ----
     const int ntiles32 = p.Np / 32;

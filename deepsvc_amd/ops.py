@@ -60,6 +60,11 @@ _fork_pools = _threading.local()
 USE_FORKS = [_os.environ.get("DSVC_FORKS", "") != ""]   # opt-in: measured 17.15 vs 17.6 fps (event edges cost more than the overlap)
 
 
+def set_option(key, value):
+    """Kernel-selection switch of the conv dispatcher (include/dsvc.h: dsvc_set_option); returns the previous value."""
+    return N.check(N.lib().dsvc_set_option(key.encode(), int(value)), "set_option")
+
+
 def run_parallel(fns):
     """Run independent launch sequences concurrently: branch 0 on the current stream, the others on side streams that
     fork from it and join back.  Eagerly this overlaps tiny latency-bound kernels; under HIP-graph capture the forks

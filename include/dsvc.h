@@ -48,6 +48,14 @@ const char* dsvc_last_error(void);
 int dsvc_version(void);
 /* number of HIP devices visible (0 when none / no driver); never throws */
 int dsvc_device_count(void);
+/* Kernel-selection switches of dsvc_conv2d, for A/B measurements and tests from one process (no reference
+ * counterpart: the reference has one cuDNN path).  Keys: "specialised" (1: conv1x1 / conv3x3_ws / conv3x3_pp /
+ * conv3x3_direct may take a launch, 0: generic kernel only), "pp", "ws", "conv1x1", "direct" (each 0/1),
+ * "direct_max_pix", "ws_waves4", "ws_direct_store".  Defaults come from the environment at load time
+ * (DSVC_NO_WS, DSVC_NO_PP, DSVC_DIRECT, DSVC_DIRECT_MAX_PIX, DSVC_WS_WAVES4, DSVC_WS_DIRECT).
+ * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
+ * fp32 mode; in bf16 mode they agree within the bf16 tolerance of the tests. */
+int dsvc_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution family (one MFMA implicit-GEMM kernel, fused epilogue).

@@ -188,6 +188,48 @@ def test_conv3x3_pingpong_kernel(segs, cout, B, H, W, pre, act, nres):
     report_close("pp vs ws", got, other, 1e-2, 1e-2 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,act,res,out_dt", [
+    ((96, 48), ("f32", "f32"), 96, 1, 68, 120, 3, None, "bf16"),          # cc_mean/cc_scale first layer (GELU)
+    ((96,), ("bf16",), 64, 1, 68, 120, 3, None, "bf16"),                  # hidden layers
+    ((64,), ("bf16",), 32, 1, 17, 30, 3, None, "bf16"),
+    ((32,), ("bf16",), 12, 1, 68, 120, 0, None, "f32"),                   # last layer: 12 channels, fp32 out
+    ((96, 48, 16), ("f32", "f32", "bf16"), 96, 1, 34, 60, 3, None, "bf16"),   # three mixed segments, short chunks
+    ((96, 8), ("f32", "f32"), 48, 2, 9, 33, 5, "f32", "f32"),             # lrp tail: 0.5*tanh + fp32 residual, batch 2
+    ((64,), ("bf16",), 224, 1, 5, 7, 1, "bf16", "bf16"),                  # 7 N-tiles, tiny image, bf16 residual
+    ((64, 32, 8), ("f32", "f32", "f32"), 8, 1, 68, 120, 4, None, "f32"),  # sigmoid, 8 channels
+])
+def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res, out_dt):
+    """Small-image bf16 3x3 convs (the slice-scan nets) can take the barrier-free kernel whose MFMA fragments are loaded
+    straight from global memory (csrc/conv3x3_direct.hip): mixed fp32/bf16 segments, short channel chunks, ragged
+    row ends, every activation, residual and output type it accepts -- against torch on bf16-rounded operands."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) * 7 + cout + W)
+    bf = torch.bfloat16
+    dts = {"f32": torch.float32, "bf16": bf}
+    ops.set_precision("bf16")
+    was = ops.set_option("direct", 1)            # opt-in kernel (slower end to end on the scan nets so far)
+    try:
+        m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        ins = [_act(x, dts[t]) for x, t in zip(xs, seg_dt)]
+        r = torch.randn(B, cout, H, W) if res else None
+        kw = dict(act=act, slope=0.05)
+        if res:
+            kw["res1"] = _act(r, dts[res])
+        got = m.run(ins if len(ins) > 1 else ins[0], out_dtype=dts[out_dt], **kw).nchw().float().cpu()
+    finally:
+        ops.set_option("direct", was)
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    xb = torch.cat([x.to(bf).float() for x in xs], 1)
+    want = _torch_act(F.conv2d(xb, w, b, padding=1), act, 0.05)
+    if res:
+        want = want + (r.to(bf).float() if res == "bf16" else r)
+    tol = (2e-2 if out_dt == "bf16" else 5e-3) * float(want.abs().max())
+    report_close("direct vs torch", got, want, 2e-2 if out_dt == "bf16" else 5e-3, tol)
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
 def test_conv1x1_streaming_kernel(cin, cout):
     """Large bf16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,
