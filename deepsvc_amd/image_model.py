@@ -24,7 +24,7 @@ from .modules import Conv2d, Deconv5x5s2, ResBottleneckBlock, conv, get_scale_ta
 from .ops import Act, to_act
 
 F32 = torch.float32
-_CODER_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="dsvc-rans")   # ctypes calls release the GIL
+_CODER_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="dsvc-rans")   # ctypes calls release the GIL; 2 per GOP lane
 
 
 class PendingStrings(dict):
@@ -285,6 +285,11 @@ class ChannelSplitICIP2020ResB(nn.Module):
             g.replay()
         else:
             fn()
+
+    def scan_graphs_ready(self, B, h, w, device):
+        key = (B, h, w, str(device), ops.RT.mode)
+        plan = self.__dict__.get("_plans", {}).get(key)
+        return plan is not None and plan.epoch == ops.PACK_EPOCH[0] and all(k in plan.graphs for k in self._segments(plan))
 
     def capture_scan_graphs(self, B, h, w, device):
         """Capture the scan segments of this codec at latent shape (h, w).  Must be called from a quiescent point (no

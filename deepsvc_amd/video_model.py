@@ -19,7 +19,7 @@ from .modules import (ME_Spynet, RefineNet, Reconstruction, FeatureExtraction, I
 from .ops import Act, to_act
 
 F32 = torch.float32
-_DECODE_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dsvc-resdec")
+_DECODE_POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="dsvc-resdec")   # one per concurrent GOP lane (bench.py --lanes)
 
 
 class DeepSVC(nn.Module):
@@ -52,6 +52,13 @@ class DeepSVC(nn.Module):
         `predict_fea + recon_res` rides on the refine net's last conv as a second residual."""
         fea = self.RefineResiNet.run(res_coarse, ref, extra_residual=predict_fea)
         return self.enhance.run([fea, warp_fea])
+
+    def graphs_ready(self, B, H, W, device):
+        """True once every scan segment of both codecs has a captured HIP graph for frames of (padded) size HxW --
+        from then on compress()/decompress() never capture again unless weights are repacked."""
+        if not ops.USE_GRAPHS[0]:
+            return True
+        return all(codec.scan_graphs_ready(B, H // 16, W // 16, device) for codec in (self.mv_codec, self.res_codec))
 
     def _maybe_capture_graphs(self, ref):
         """HIP-graph capture of the codecs' scan segments, done here (main thread, no coder/decoder thread in flight)
