@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=2, help="independent GOP pipelines in flight per GPU (1 = strictly sequential frames)")
+    ap.add_argument("--lanes", type=int, default=4, help="independent GOP pipelines in flight per GPU (1 = strictly sequential frames)")
     ap.add_argument("--precision", default=os.environ.get("DSVC_PRECISION", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--size", default="1080x1920")
     ap.add_argument("--no-cpu-baseline", action="store_true")

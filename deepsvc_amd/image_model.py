@@ -24,7 +24,7 @@ from .modules import Conv2d, Deconv5x5s2, ResBottleneckBlock, conv, get_scale_ta
 from .ops import Act, to_act
 
 F32 = torch.float32
-_CODER_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="dsvc-rans")   # ctypes calls release the GIL; 2 per GOP lane
+_CODER_POOL = ThreadPoolExecutor(max_workers=12, thread_name_prefix="dsvc-rans")   # ctypes calls release the GIL; 2 per GOP lane, up to 6 lanes
 
 
 class PendingStrings(dict):

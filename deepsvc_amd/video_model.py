@@ -19,7 +19,7 @@ from .modules import (ME_Spynet, RefineNet, Reconstruction, FeatureExtraction, I
 from .ops import Act, to_act
 
 F32 = torch.float32
-_DECODE_POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="dsvc-resdec")   # one per concurrent GOP lane (bench.py --lanes)
+_DECODE_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="dsvc-resdec")   # one per concurrent GOP lane (bench.py --lanes)
 
 
 class DeepSVC(nn.Module):
