@@ -67,7 +67,10 @@ __device__ __forceinline__ uint4 act_bf16x8(uint4 val, float slope) {
     return make_uint4(u[0], u[1], u[2], u[3]);
 }
 
-template <int NT, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
+// NCH: 32-channel input chunks (2: the schedule above; 1: inputs of <= 32 channels, phases M0 | E+S0 only).
+// HEAD: narrow output head (Cout <= 8, any activation, fp32 or bf16 out, optional residual of either type): one N-tile
+// is computed and the lanes that hold channels 0..7 store them element-wise.
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
 __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
                                                               float pre_slope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,15 +84,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
 #endif
     const int r = lane & 31, h = lane >> 5;
     char* lds_w = smem;                                                       // [chunk 2][tap 9][NTN] rows of 80 B
-    char* lds_a = smem + 2 * 9 * NTN * ROWB + g * (PP_NPATCH * ROWB);          // this group's patch
-    float* lds_bias = (float*)(smem + 2 * 9 * NTN * ROWB + 2 * PP_NPATCH * ROWB);   // NTN floats
+    char* lds_a = smem + NCH * 9 * NTN * ROWB + g * (PP_NPATCH * ROWB);        // this group's patch
+    float* lds_bias = (float*)(smem + NCH * 9 * NTN * ROWB + 2 * PP_NPATCH * ROWB);   // NTN floats
     const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
     const rsrc_t rr1 = make_rsrc(HAS_R1 ? p.res1 : p.out, HAS_R1 ? p.res1_bytes : p.out_bytes);
     const rsrc_t rr2 = make_rsrc(HAS_R2 ? p.res2 : p.out, HAS_R2 ? p.res2_bytes : p.out_bytes);
 
     // ---- weights: staged once (rows are [chunk][tap][Np == NTN] x 64 B in global memory) ----
     {
-        const int nrows = 2 * 9 * NTN, q = tid & 3;
+        const int nrows = NCH * 9 * NTN, q = tid & 3;
         for (int base = tid >> 2; base < nrows; base += 128 * 6) {
             uint4 v[6];
 #pragma unroll
@@ -130,11 +133,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
         const ConvSeg& sg = p.seg[(p.nseg > 1 && ch >= p.seg[1].chunk0) ? 1 : 0];
         const rsrc_t rin = make_rsrc(sg.ptr, sg.bytes);
         const unsigned ldb = (unsigned)sg.ld * 2, cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
+        const bool cok = (ch - sg.chunk0) * 32 + q * 8 < sg.C;             // short chunk (C % 8 == 0): the tail reads zeros
         const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;        // scalar; negative only where inb is false
 #pragma unroll
         for (int j = 0; j < PP_PFV; ++j) {
             const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
-            const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PP_PFV - 1 || last_ok);   // padding reads zeros
+            const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PP_PFV - 1 || last_ok) && cok;   // padding reads zeros
             pf[j] = buf_load16(rin, inb ? __umul24((unsigned)(base_pix + pp_pix[j]), ldb) + cb : OOB);
         }
     };
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
     TileOrg cur = tile_origin(min(tile_of(0), ntiles - 1)), nxt = tile_origin(min(tile_of(1), ntiles - 1));
     load_chunk(cur, 0, pf0);
     store_chunk(pf0);
-    load_chunk(cur, 1, pf1);
+    if constexpr (NCH == 2) load_chunk(cur, 1, pf1);
     load_chunk(nxt, 0, pf0);
     if constexpr (HAS_R1) load_res(cur, tile_of(0) < ntiles);
     lds_barrier();                       // weights, bias and both groups' first patches are in place
@@ -259,15 +263,41 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
         // ---- M0 ----
         mfma_phase(0, true);
         lds_barrier();
-        // ---- S1 (+ prefetch: next tile's chunk 1) ----
-        store_chunk(pf1);
-        load_chunk(nxt, 1, pf1);
-        lds_barrier();
-        // ---- M1 ----
-        mfma_phase(1, false);
-        lds_barrier();
+        if constexpr (NCH == 2) {
+            // ---- S1 (+ prefetch: next tile's chunk 1) ----
+            store_chunk(pf1);
+            load_chunk(nxt, 1, pf1);
+            lds_barrier();
+            // ---- M1 ----
+            mfma_phase(1, false);
+            lds_barrier();
+        }
         // ---- E + S0 (+ prefetch: chunk 0 of the tile after next, the next tile's residual) ----
-        {
+        if constexpr (HEAD) {
+            // narrow head: after the first swap level the h == 0 lanes hold channels 0..7 of pixel r (bias already in acc)
+#define PP_HEAD_ROW(M)                                                                                              \
+    {                                                                                                               \
+        float v[8];                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+            const float xq = acc[M][0][j], yq = acc[M][0][4 + j];                                                   \
+            const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false); \
+            const unsigned lo_ = sw.x, hi_ = sw.y;                                                                  \
+            v[j] = __builtin_bit_cast(float, lo_); v[4 + j] = __builtin_bit_cast(float, hi_);                       \
+        }                                                                                                           \
+        const int oy = cur.oy0 + wg * MTW + M, ox = cur.ox0 + r;                                                    \
+        if (valid && h == 0 && oy < p.Ho && ox < p.Wo) {                                                            \
+            const int64_t opix = ((int64_t)cur.b * p.Ho + oy) * p.Wo + ox;                                          \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                           \
+                if (j < p.Cout) {                                                                                   \
+                    float val = apply_act(v[j], p.act, p.slope);                                                    \
+                    if (p.res1) val += load_elem(p.res1, p.res1_dtype, opix * p.res1_ld + j);                       \
+                    store_elem(p.out, p.out_dtype, opix * p.out_ld + j, val);                                       \
+                }                                                                                                   \
+        }                                                                                                           \
+    }
+            PP_HEAD_ROW(0) PP_HEAD_ROW(1)
+#undef PP_HEAD_ROW
+        } else {
             unsigned o_out[MTW][2], o_r2[MTW][2];
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
@@ -338,11 +368,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
     if (!g) lds_barrier();               // matches group 1's leading barrier
 }
 
-template <int NT, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
 int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, float pre_slope) {
-    const size_t lds = (size_t)2 * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)NT * 32 * sizeof(float);
+    const size_t lds = (size_t)NCH * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)NT * 32 * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<NT, PRE, ACT, HAS_R1, HAS_R2>;
+    auto kern = conv3x3_pp_kernel<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
@@ -359,9 +389,9 @@ int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, 
 
 template <int NT, bool PRE, bool ACT>
 int launch_pp_res(hipStream_t st, const ConvParams& p, int ntiles, float a, float b) {
-    if (p.res1 && p.res2) return launch_pp<NT, PRE, ACT, true, true>(st, p, ntiles, a, b);
-    if (p.res1) return launch_pp<NT, PRE, ACT, true, false>(st, p, ntiles, a, b);
-    return launch_pp<NT, PRE, ACT, false, false>(st, p, ntiles, a, b);
+    if (p.res1 && p.res2) return launch_pp<NT, 2, false, PRE, ACT, true, true>(st, p, ntiles, a, b);
+    if (p.res1) return launch_pp<NT, 2, false, PRE, ACT, true, false>(st, p, ntiles, a, b);
+    return launch_pp<NT, 2, false, PRE, ACT, false, false>(st, p, ntiles, a, b);
 }
 
 template <int NT>
@@ -384,23 +414,37 @@ bool vec16_ok(const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (l
 // returns 1 when the shape is not covered (caller tries conv3x3_ws / the generic kernel), else DSVC_OK / error
 int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
     if (d->compute != DSVC_BF16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
-    if (p_in.nchunks != 2 || p_in.nseg > 2 || (d->Cout != 32 && d->Cout != 64) || d->res1_scale) return 1;
-    if (d->out_dtype != DSVC_BF16 || !vec16_ok(d->out, d->out_ld)) return 1;
-    if (d->res1 && (d->res1_dtype != DSVC_BF16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
-    if (d->res2 && (!d->res1 || d->res2_dtype != DSVC_BF16 || !vec16_ok(d->res2, d->res2_ld))) return 1;
-    for (int s = 0; s < p_in.nseg; ++s) {                          // every 64-B chunk is a full, aligned 32-channel vector row
+    if (p_in.nchunks < 1 || p_in.nchunks > 2 || p_in.nseg > 2 || d->res1_scale) return 1;
+    for (int s = 0; s < p_in.nseg; ++s) {                          // every pixel's chunk row is an aligned run of 16-B vectors
         const ConvSeg& sg = p_in.seg[s];
-        if (sg.dtype != DSVC_BF16 || (sg.C % 32) != 0 || !vec16_ok(sg.ptr, sg.ld)) return 1;
+        if (sg.dtype != DSVC_BF16 || (sg.C % 8) != 0 || !vec16_ok(sg.ptr, sg.ld)) return 1;
+        if (p_in.nchunks == 2 && (sg.C % 32) != 0) return 1;
     }
-    float act_slope, pre_slope;
-    if (!slope_of(d->act, d->slope, &act_slope) || !slope_of(d->pre_act, d->slope, &pre_slope)) return 1;
     ConvParams p = p_in;
     p.tiles_x = (p.Wo + 31) / 32;
     p.tiles_y = (p.Ho + PP_TH - 1) / PP_TH;
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;   // pixel indices go through the 24-bit multiplier
     if (ntiles < 1024) return 1;           // small images: the generic kernel's finer tiling fills the chip better
+    if (d->Cout <= 8) {                    // narrow heads (flow / frame / mask outputs): any activation, element-wise stores
+        if (d->pre_act != DSVC_ACT_NONE || d->res2) return 1;
+        return p.nchunks == 2 ? launch_pp<1, 2, true, false, false, false, false>(st, p, ntiles, 1.f, 1.f)
+                              : launch_pp<1, 1, true, false, false, false, false>(st, p, ntiles, 1.f, 1.f);
+    }
+    if (d->Cout != 32 && d->Cout != 64) return 1;
+    if (d->out_dtype != DSVC_BF16 || !vec16_ok(d->out, d->out_ld)) return 1;
+    if (d->res1 && (d->res1_dtype != DSVC_BF16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
+    if (d->res2 && (!d->res1 || d->res2_dtype != DSVC_BF16 || !vec16_ok(d->res2, d->res2_ld))) return 1;
+    float act_slope, pre_slope;
+    if (!slope_of(d->act, d->slope, &act_slope) || !slope_of(d->pre_act, d->slope, &pre_slope)) return 1;
     const bool pre = d->pre_act != DSVC_ACT_NONE, act = d->act != DSVC_ACT_NONE;
+    if (p.nchunks == 1) {                  // first-layer convs (8 / 16 / 32 input channels): no fused pre-activation or residual
+        if (pre || d->res1) return 1;
+        if (d->Cout == 64) return act ? launch_pp<2, 1, false, false, true, false, false>(st, p, ntiles, act_slope, 1.f)
+                                      : launch_pp<2, 1, false, false, false, false, false>(st, p, ntiles, 1.f, 1.f);
+        return act ? launch_pp<1, 1, false, false, true, false, false>(st, p, ntiles, act_slope, 1.f)
+                   : launch_pp<1, 1, false, false, false, false, false>(st, p, ntiles, 1.f, 1.f);
+    }
     if (d->Cout == 64) return launch_pp_act<2>(st, p, ntiles, pre, act, act_slope, pre_slope);
     return launch_pp_act<1>(st, p, ntiles, pre, act, act_slope, pre_slope);
 }

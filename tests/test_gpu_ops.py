@@ -151,6 +151,10 @@ def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
     ((32, 32), 64, 1, 250, 1090, 0, 2, 0),   # two 32-channel segments (virtual cat)
     ((64,), 32, 1, 256, 1056, 0, 2, 1),      # 32 output channels
     ((64,), 64, 2, 130, 1000, 2, 0, 1),      # batch of two
+    ((8,), 64, 1, 256, 1030, 0, 0, 0),       # single short chunk (first-layer convs): 8 / 16 / 32 input channels
+    ((16,), 64, 1, 250, 1100, 0, 2, 0),
+    ((32,), 32, 1, 264, 1000, 0, 2, 0),
+    ((32,), 64, 1, 256, 1024, 0, 0, 0),
 ])
 def test_conv3x3_pingpong_kernel(segs, cout, B, H, W, pre, act, nres):
     """The 64-channel bf16 ResBlock family takes the two-group phase-skewed kernel (csrc/conv3x3_pp.hip): every
@@ -186,6 +190,45 @@ def test_conv3x3_pingpong_kernel(segs, cout, B, H, W, pre, act, nres):
     tol = 2e-2 * float(want.abs().max())
     report_close("pp vs torch", got, want, 2e-2, tol)
     report_close("pp vs ws", got, other, 1e-2, 1e-2 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,H,W,act,res,out_dt", [
+    (64, 3, 256, 1024, 4, None, "f32"),      # sigmoid mask heads
+    (64, 3, 250, 1100, 0, None, "f32"),      # frame heads
+    (64, 2, 251, 1043, 0, "f32", "f32"),     # flow head + fp32 residual
+    (32, 3, 264, 1000, 0, None, "f32"),      # single-chunk input
+    (64, 8, 256, 1056, 1, "bf16", "bf16"),   # 8 channels, bf16 out + bf16 residual
+])
+def test_conv3x3_pingpong_narrow_head(cin, cout, H, W, act, res, out_dt):
+    """Narrow output heads (Cout <= 8) on the ping-pong kernel: one N-tile, element-wise fp32/bf16 stores."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(cin + cout + W)
+    bf = torch.bfloat16
+    dts = {"f32": torch.float32, "bf16": bf}
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(cin, cout, 3, 1, 1).to(DEV)
+        x = torch.randn(1, cin, H, W)
+        r = torch.randn(1, cout, H, W) if res else None
+        kw = dict(act=act, slope=0.05)
+        if res:
+            kw["res1"] = _act(r, dts[res])
+        got = m.run(_act(x, bf), out_dtype=dts[out_dt], **kw).nchw().float().cpu()
+        was = ops.set_option("pp", 0)
+        try:
+            other = m.run(_act(x, bf), out_dtype=dts[out_dt], **kw).nchw().float().cpu()     # weight-stationary kernel
+        finally:
+            ops.set_option("pp", was)
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    want = _torch_act(F.conv2d(x.to(bf).float(), w, b, padding=1), act, 0.05)
+    if res:
+        want = want + (r.to(bf).float() if res == "bf16" else r)
+    rt = 2e-2 if out_dt == "bf16" else 5e-3
+    report_close("head vs torch", got, want, rt, rt * float(want.abs().max()))
+    report_close("head vs ws", got, other, rt, rt * float(want.abs().max()))
 
 
 @pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,act,res,out_dt", [
