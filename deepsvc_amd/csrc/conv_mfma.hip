@@ -51,8 +51,15 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     const int PH = (TH - 1) * p.stride + p.kh, PW = (TW - 1) * p.stride + p.kw;
     const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
     const int npatch = PH * PW;
+    // LDS image of the patch: row-major pixels at the 80-B pitch.  For stride 2 the even and the odd columns of a patch
+    // row are stored apart (pitch PWL = 2 * ceil(PW/2)), so that the fragment of tap kx -- input columns 2r + kx,
+    // r = lane & 31 -- is a UNIT-stride run again: with interleaved columns the 160-B lane stride made every
+    // ds_read_b128 a two-way bank conflict (5x5 s2 analysis convs ran at ~190 TFLOP/s).
+    const bool s2 = p.stride == 2;
+    const int PWh = (PW + 1) >> 1, PWL = s2 ? 2 * PWh : PW;
+    auto lds_row = [&](int py, int px) { return py * PWL + (s2 ? (px & 1) * PWh + (px >> 1) : px); };
     char* lds_a = smem;
-    char* lds_w = smem + (size_t)npatch * ROWB;
+    char* lds_w = smem + (size_t)PH * PWL * ROWB;
     const int ntaps = p.kh * p.kw;
 
     f32x16 acc[MT][NT];
@@ -71,7 +78,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     // fragment read offsets: lane (r,h) takes bytes [32h + 16ks, +16) of row r
     int a_off[MT], b_off[NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a_off[m] = (((wave * MT + m) * p.stride) * PW + r * p.stride) * ROWB + h * 32;
+    for (int m = 0; m < MT; ++m) a_off[m] = (((wave * MT + m) * p.stride) * PWL + r) * ROWB + h * 32;
 #pragma unroll
     for (int n = 0; n < NT; ++n) b_off[n] = (n * 32 + r) * ROWB + h * 32;
 
@@ -94,9 +101,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             int py = py0, px = px0;
             for (int base = pix0; base < npatch; base += 64 * PB) {
                 uint4 v[PB];
+                int lr[PB];
 #pragma unroll
                 for (int j = 0; j < PB; ++j) {
                     const int iy = iy0 + py, ix = ix0 + px;
+                    lr[j] = lds_row(py, px);
                     const bool inb = qvalid && base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                     v[j] = buf_load16(rs, inb ? img + ((unsigned)iy * p.W + ix) * pitch : OOB);
                     px += dpx; py += dpy;
@@ -122,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < PB; ++j)
-                    if (base + 64 * j < npatch) *(uint4*)(lds_a + (base + 64 * j) * ROWB + q * 16) = v[j];
+                    if (base + 64 * j < npatch) *(uint4*)(lds_a + lr[j] * ROWB + q * 16) = v[j];
             }
         } else {
             int py = py0, px = px0;
@@ -139,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     }
                     val = pack_vec<CT, EPV>(vals);
                 }
-                *(uint4*)(lds_a + pix * ROWB + q * 16) = val;
+                *(uint4*)(lds_a + lds_row(py, px) * ROWB + q * 16) = val;
                 px += dpx; py += dpy;
                 if (px >= PW) { px -= PW; ++py; }
             }
@@ -177,7 +186,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             struct Frags { uint4 a[2][MT], b[2][NT]; };
             int rt = 0;                                   // next tap (within the staged group) to read
             auto read_tap = [&](Frags& f) {
-                const int tap_off = (ky * PW + kx) * ROWB;
+                const int tap_off = (ky * PWL + (s2 ? (kx & 1) * PWh + (kx >> 1) : kx)) * ROWB;
                 const char* wt = lds_w + rt * NTN * ROWB;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -388,7 +397,8 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     p.tiles_y = (p.Ho + TH - 1) / TH;
     const int ngroups = (ntiles32 + NT - 1) / NT;
     const int PH = (TH - 1) * d->stride + d->kh, PW = (TW - 1) * d->stride + d->kw;
-    const size_t lds_a = (size_t)PH * PW * ROWB;
+    const int PWL = d->stride == 2 ? 2 * ((PW + 1) / 2) : PW;      // LDS row pitch in pixels (stride 2: even | odd columns)
+    const size_t lds_a = (size_t)PH * PWL * ROWB;
     const int ntaps = d->kh * d->kw;
     const size_t budget = 78 * 1024;  // two workgroups per CU
     p.tapg = ntaps;

@@ -25,6 +25,11 @@ SHAPES = [  # (name, segs, cout, k, stride, H, W, kwargs)
     ("5x5s2 70->96 @1/1", (70,), 96, 5, 2, 1088, 1920, {}),
     ("3x3 64->64 @1/16", (64,), 64, 3, 1, 68, 120, {}),
     ("3x3 96->12 @1/16", (96,), 12, 3, 1, 68, 120, {}),
+    ("5x5s2 8+64+8->96 @1/1", (8, 64, 8), 96, 5, 2, 1088, 1920, {}),
+    ("5x5s2 96->96 @1/2", (96,), 96, 5, 2, 544, 960, {}),
+    ("3x3 64+64->64 @1/1", (64, 64), 64, 3, 1, 1088, 1920, {}),
+    ("3x3 128->128 @1/4 +res", (128,), 128, 3, 1, 272, 480, {"res": True}),
+    ("7x7 32->64 @1/1", (32,), 64, 7, 1, 1088, 1920, {}),
 ]
 
 
