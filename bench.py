@@ -220,6 +220,7 @@ def main():
             "config": {"workload": f"{w}x{h} (padded {W_pad}x{H_pad}) GOP={GOP} P-frames, W0 synthetic PSNR weight set, "
                                    f"compress+decompress per frame, GOPs sharded across ranks, {args.lanes} independent GOP lane(s) in flight per GPU "
                                    f"(one step = one P-frame on every lane)", "precision": args.precision, "gop_lanes": args.lanes,
+                       "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 2**30,
                        "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
                        "whole_frame_tflops": fps * FLOP_PER_PX_GOP7 * H_pad * W_pad / 1e12 / world},
             "roofline": roof,

@@ -197,3 +197,55 @@ def test_bf16_mode_end_to_end(model, oracle_w0):
           f"PSNR(gpu,oracle) {psnr(dec_g[1].cpu(), dec_o[1]):.1f} dB")
     assert abs(b_g - b_o) <= 0.03 * b_o
     assert abs(p_g - p_o) <= 0.1
+
+
+def test_full_size_1080p_roundtrip_properties(oracle_w0):
+    """BASELINE.json configs[1] size (1920x1080 -> padded 1088x1920), where the CPU oracle is too slow to be the
+    checker: size-independent properties of the real bitstream path instead.
+      * encode -> decode round trip: the decoder's latents y_hat (both codecs) are bit-identical to the encoder's;
+      * determinism / idempotence: decoding the same strings twice gives bit-identical frames and features;
+      * a second, chained P-frame (feature and reference from the decoder) behaves the same;
+      * bf16 mode stays inside the north-star tolerance of fp32 mode on the same inputs: |d bytes| <= 1 %, and the two
+        reconstructions agree to > 40 dB."""
+    from deepsvc_amd import ops, synth
+    from deepsvc_amd.modules import pad
+
+    def run(precision):
+        ops.set_precision(precision)
+        try:
+            model = synth.make_model("W0")
+            model.update(force=True)
+            model = model.to(DEV)
+            frames = [pad(f.to(DEV), 64) for f in synth.make_frames(1080, 1920, 3, seed=7)]
+            sms = [None] + [synth.make_sm_fea(1088, 1920, t, seed=7).to(DEV) for t in (1, 2)]
+            ref, feat, out = frames[0], None, []
+            for t in (1, 2):
+                mv, res = model.compress(ref, frames[t], sms[t], feat)
+                mv, res = {k: mv[k] for k in ("strings", "shape")}, {k: res[k] for k in ("strings", "shape")}   # joins the coders
+                torch.cuda.synchronize()
+                enc_lat = [c._plan(1, 68, 120, torch.device(DEV)).y_hat.buf.clone() for c in (model.mv_codec, model.res_codec)]
+                f1, r1, w1, p1 = model.decompress(ref, mv, res, sms[t], feat)
+                torch.cuda.synchronize()
+                dec_lat = [c._plan(1, 68, 120, torch.device(DEV)).y_hat.buf.clone() for c in (model.mv_codec, model.res_codec)]
+                f2, r2, w2, p2 = model.decompress(ref, mv, res, sms[t], feat)
+                torch.cuda.synchronize()
+                for a, b, what in zip(enc_lat, dec_lat, ("mv", "res")):
+                    assert torch.equal(a, b), f"{precision} frame {t}: decoder {what} latents differ from the encoder's"
+                assert torch.equal(r1, r2) and torch.equal(w1, w2) and torch.equal(p1, p2), "decode is not deterministic"
+                assert torch.equal(f1.float(), f2.float())
+                nbytes = sum(len(s[0]) for s in mv["strings"]) + sum(len(s[0]) for s in res["strings"])
+                assert nbytes > 1000 and tuple(mv["shape"]) == (17, 30)
+                assert torch.isfinite(r1).all() and float(r1.min()) >= 0.0 and float(r1.max()) <= 1.0
+                out.append((nbytes, r1.float().cpu()))
+                ref, feat = r1, f1
+            return out
+        finally:
+            ops.set_precision("fp32")
+
+    a, b = run("fp32"), run("bf16")
+    for t, ((na, ra), (nb, rb)) in enumerate(zip(a, b), 1):
+        assert abs(nb - na) <= 0.01 * na, f"frame {t}: bf16 {nb} B vs fp32 {na} B"
+        mse = float(((ra - rb) ** 2).mean())
+        psnr = 99.0 if mse == 0 else -10.0 * float(np.log10(mse))
+        print(f"1080p frame {t}: fp32 {na} B, bf16 {nb} B ({100.0 * (nb - na) / na:+.3f} %), PSNR(bf16 recon, fp32 recon) = {psnr:.1f} dB")
+        assert psnr > 40.0
