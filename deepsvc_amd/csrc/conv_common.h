@@ -1,4 +1,4 @@
-// conv_common.h -- parameter block and fused epilogue shared by the conv kernels (conv_mfma.hip, conv3x3_rs.hip).
+// conv_common.h -- parameter block and fused epilogue shared by the conv kernels (conv_mfma.hip, conv3x3_ws.hip / conv3x3_pp.hip / conv1x1.hip).
 #pragma once
 #include "common.h"
 
