@@ -59,6 +59,11 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
 // 8 packed bf16 -> act(x) = max(x, x*slope) -> 8 packed bf16 (slope 0: ReLU; 0<slope<1: LeakyReLU)
 __device__ __forceinline__ uint4 act_bf16x8(uint4 val, float slope) {
     unsigned u[4] = {val.x, val.y, val.z, val.w};
+    if (slope == 0.f) {   // ReLU (wave-uniform): a bf16 is negative iff its int16 image is, so one packed integer max per pair
+#pragma unroll            // (-0.0 -> +0.0, NaNs with the sign bit set -> 0: neither occurs on this path)
+        for (int k = 0; k < 4; ++k) asm("v_pk_max_i16 %0, %1, 0" : "=v"(u[k]) : "v"(u[k]));
+        return make_uint4(u[0], u[1], u[2], u[3]);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
