@@ -83,14 +83,14 @@ class _ScanPlan:
     """Static device/pinned buffers of one codec at one latent shape: graph-captured scan segments address them."""
 
     def __init__(self, codec, B, h, w, device):
-        Nc, d = codec.N, codec.slice_depth
+        Nc, Mc, d = codec.N, codec.M, codec.slice_depth          # hyper-latent z: N channels; latent y: M channels
         self.device, self.epoch, self.graphs = device, -1, {}
         act = lambda H, W, C: ops.new_act(B, H, W, C, F32, device)
-        self.y, self.y_hat, self.means, self.scales = act(h, w, Nc), act(h, w, Nc), act(h, w, Nc), act(h, w, Nc)
+        self.y, self.y_hat, self.means, self.scales = act(h, w, Mc), act(h, w, Mc), act(h, w, Mc), act(h, w, Mc)
         self.z_hat = act(h // 4, w // 4, Nc)
         self.mus = [act(h, w, d) for _ in range(codec.num_slices)]
         self.scs = [act(h, w, d) for _ in range(codec.num_slices)]
-        self.nz, self.ny, self.ns = B * Nc * (h // 4) * (w // 4), B * Nc * h * w, B * d * h * w
+        self.nz, self.ny, self.ns = B * Nc * (h // 4) * (w // 4), B * Mc * h * w, B * d * h * w
         k = codec.max_support_slices
         self.groups = [[i] for i in range(min(k, codec.num_slices))] + \
                       ([list(range(k, codec.num_slices))] if codec.num_slices > k else [])
@@ -113,30 +113,33 @@ def deconv(cin, cout, kernel_size=5, stride=2):
     return Deconv5x5s2(cin, cout)
 
 
-def _gelu_stack(widths):
-    """conv3x3(s1) stack with GELU between layers, keyed 0,2,4,... like the reference's nn.Sequential."""
+def _gelu_stack(widths, act=nn.GELU):
+    """conv3x3(s1) stack with an activation between layers, keyed 0,2,4,... like the reference's nn.Sequential."""
     layers = []
     for i, (a, b) in enumerate(zip(widths[:-1], widths[1:])):
         layers.append(conv(a, b, stride=1, kernel_size=3))
         if i < len(widths) - 2:
-            layers.append(nn.GELU())
+            layers.append(act())
     return nn.Sequential(*layers)
 
 
-def _run_gelu_stack(stack, segments, out=None, **last_epilogue):
+def _run_stack(stack, segments, out=None, hidden_act=N.ACT_GELU, hidden_slope=0.01, **last_epilogue):
+    """conv3x3 stack of the slice scan: `hidden_act` after every conv but the last, whose fused epilogue is the caller's."""
     convs = [m for m in stack if isinstance(m, Conv2d)]
     x = segments
     for c in convs[:-1]:
         # hidden activations in the storage type: in bf16 mode they would be rounded to bf16 when staged for the MFMA
         # anyway (same single rounding), and bf16 storage puts the next layer on the conv's fast staging path
-        x = c.run(x, act=N.ACT_GELU, out_dtype=ops.RT.storage)
+        x = c.run(x, act=hidden_act, slope=hidden_slope, out_dtype=ops.RT.storage)
     return convs[-1].run(x, out, out_dtype=F32, **last_epilogue)
 
 
 class ChannelSplitICIP2020ResB(nn.Module):
+    _stack_act = (N.ACT_GELU, 0.01)      # activation between the convs of the cc_mean / cc_scale / lrp stacks
+
     def __init__(self, in_ch=3, N=192, out_ch=3):
         super().__init__()
-        self.N = N
+        self.N = self.M = N              # hyper-latent and latent channel counts (they differ in ICIP2020ResB)
         self.num_slices = 8
         self.max_support_slices = 4
         d = self.N // self.num_slices
@@ -203,12 +206,14 @@ class ChannelSplitICIP2020ResB(nn.Module):
         x = self.h_a[4].run(x, act=N.ACT_GELU, out_dtype=F32)
         return self.h_a[6].run(x, out_dtype=F32)
 
-    @staticmethod
-    def _h_s(net, z_hat, out=None):
+    def _h_s(self, net, z_hat, out=None):
         x = net[0].run(z_hat, act=N.ACT_GELU, out_dtype=F32)
         x = net[2].run(x, act=N.ACT_GELU, out_dtype=F32)
         x = net[4].run(x, act=N.ACT_GELU, out_dtype=F32)
         return net[6].run(x, out, out_dtype=F32)
+
+    def _stack(self, stack, segments, out=None, **last_epilogue):
+        return _run_stack(stack, segments, out, self._stack_act[0], self._stack_act[1], **last_epilogue)
 
     def _support(self, latent, y_hat, i):
         k = min(i, self.max_support_slices)
@@ -217,15 +222,15 @@ class ChannelSplitICIP2020ResB(nn.Module):
     def _slice_params(self, i, means, scales, y_hat, mu_out=None, sc_out=None):
         """mu_i, sigma_i: two independent 4-conv stacks -> forked onto two streams."""
         return ops.run_parallel([
-            lambda: _run_gelu_stack(self.cc_mean_transforms[i], self._support(means, y_hat, i), out=mu_out),
-            lambda: _run_gelu_stack(self.cc_scale_transforms[i], self._support(scales, y_hat, i), out=sc_out)])
+            lambda: self._stack(self.cc_mean_transforms[i], self._support(means, y_hat, i), out=mu_out),
+            lambda: self._stack(self.cc_scale_transforms[i], self._support(scales, y_hat, i), out=sc_out)])
 
     def _group_params(self, ws, group):
         """mu_i, sigma_i for every slice of one dependency level: 2*len(group) independent 4-conv stacks, one flat fork."""
         fns = []
         for i in group:
-            fns.append(lambda i=i: _run_gelu_stack(self.cc_mean_transforms[i], self._support(ws.means, ws.y_hat, i), out=ws.mus[i]))
-            fns.append(lambda i=i: _run_gelu_stack(self.cc_scale_transforms[i], self._support(ws.scales, ws.y_hat, i), out=ws.scs[i]))
+            fns.append(lambda i=i: self._stack(self.cc_mean_transforms[i], self._support(ws.means, ws.y_hat, i), out=ws.mus[i]))
+            fns.append(lambda i=i: self._stack(self.cc_scale_transforms[i], self._support(ws.scales, ws.y_hat, i), out=ws.scs[i]))
         ops.run_parallel(fns)
 
     def _lrp(self, i, means, y_hat):
@@ -236,7 +241,7 @@ class ChannelSplitICIP2020ResB(nn.Module):
             segs = [means, y_hat.ch(0, (i + 1) * d)]
         else:
             segs = [means, y_hat.ch(0, self.max_support_slices * d), cur]
-        _run_gelu_stack(self.lrp_transforms[i], segs, out=cur, act=N.ACT_HALF_TANH, res1=cur)
+        self._stack(self.lrp_transforms[i], segs, out=cur, act=N.ACT_HALF_TANH, res1=cur)
 
     def _hyper(self, z_hat):
         return self._h_s(self.h_scale_s, z_hat), self._h_s(self.h_mean_s, z_hat)
@@ -472,3 +477,64 @@ class ChannelSplitICIP2020ResB(nn.Module):
 
     def aux_loss(self):
         return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+
+class ICIP2020ResB(ChannelSplitICIP2020ResB):
+    """MI355X-native I-frame codec (reference image_model.py:331-619): image [B,3,H,W] -> latent y
+    (M = 320 channels @1/16) -> hyper-latent z (N = 192 @1/64); 10 slices of 32 channels, each conditioned on the
+    hyperprior and on the first 5 decoded slices, so the scan has depth 6 (slices 5..9 are one dependency level).
+
+    Same attribute paths / state_dict keys, `forward / compress / decompress / update / load_state_dict / aux_loss`
+    contracts and bitstream as the reference.  Everything below the layer definitions -- slice scan on static workspaces,
+    HIP graphs of the scan segments, batched decode levels, one device->host transfer per encode -- is the shared
+    machinery of `ChannelSplitICIP2020ResB`; only the transforms differ (LeakyReLU(0.01) stacks of three convs,
+    5x5/s2 convs in h_a, transposed 5x5/s2 convs in h_mean_s / h_scale_s)."""
+    _stack_act = (N.ACT_LRELU, 0.01)
+
+    def __init__(self, N=192, M=320):
+        nn.Module.__init__(self)
+        self.N, self.M = N, M
+        self.num_slices = 10
+        self.max_support_slices = 5
+        d = M // self.num_slices
+        if d * self.num_slices != M:
+            raise ValueError(f"Slice do not evenly divide latent depth ({M}/{self.num_slices})")
+        self.slice_depth = d
+        lrelu = lambda: nn.LeakyReLU(inplace=True)
+
+        def stage_list(first, make, last_out):
+            mods = [first]
+            for stage in range(3):
+                mods += [ResBottleneckBlock(N) for _ in range(3)]
+                mods.append(make(N, last_out if stage == 2 else N))
+            return nn.Sequential(*mods)
+
+        self.g_a = stage_list(conv(3, N), conv, M)                    # image_model.py:344-358
+        self.g_s = stage_list(deconv(M, N), deconv, 3)                # :360-374
+        self.h_a = nn.Sequential(conv(M, N, stride=1, kernel_size=3), lrelu(), conv(N, N), lrelu(), conv(N, N))   # :376-382
+        hyper_synthesis = lambda: nn.Sequential(deconv(N, N), lrelu(), deconv(N, 256), lrelu(),
+                                                conv(256, M, stride=1, kernel_size=3))                              # :384-398
+        self.h_mean_s, self.h_scale_s = hyper_synthesis(), hyper_synthesis()
+        k = self.max_support_slices
+        stack = lambda cin: _gelu_stack([cin, 224, 128, d], act=lrelu)                                               # :408-436
+        self.cc_mean_transforms = nn.ModuleList(stack(M + d * min(i, k)) for i in range(self.num_slices))
+        self.cc_scale_transforms = nn.ModuleList(stack(M + d * min(i, k)) for i in range(self.num_slices))
+        self.lrp_transforms = nn.ModuleList(stack(M + d * min(i + 1, k + 1)) for i in range(self.num_slices))
+        self.entropy_bottleneck = EntropyBottleneck(N)
+        self.gaussian_conditional = GaussianConditional(None)
+
+    def _h_a(self, y):
+        x = self.h_a[0].run(y, act=N.ACT_LRELU, slope=0.01, out_dtype=F32)
+        x = self.h_a[2].run(x, act=N.ACT_LRELU, slope=0.01, out_dtype=F32)
+        return self.h_a[4].run(x, out_dtype=F32)
+
+    def _h_s(self, net, z_hat, out=None):
+        x = net[0].run(z_hat, act=N.ACT_LRELU, slope=0.01, out_dtype=F32)
+        x = net[2].run(x, act=N.ACT_LRELU, slope=0.01, out_dtype=F32)
+        return net[4].run(x, out, out_dtype=F32)
+
+    def decompress(self, strings, shape):
+        """image_model.py:554-595: the reconstruction is clamped to [0, 1]."""
+        dev = self.entropy_bottleneck.quantiles.device
+        x_hat = self.run_decompress(strings, shape, dev, x_hat_dtype=F32)
+        return {"x_hat": ops.eltwise(N.EW_CLAMP01, x_hat).nchw()}

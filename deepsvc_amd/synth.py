@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CALIBRATION = os.path.join(HERE, "data", "w0_calibration.json")
+ICIP_CALIBRATION = os.path.join(HERE, "data", "icip_w0_calibration.json")
 
 
 def make_frames(H, W, n_frames, seed=1234):
@@ -65,6 +66,24 @@ def make_model(weight_set="W0", calibrated=True):
     torch.random.set_rng_state(rng)
     if calibrated:
         sd = apply_calibration(model.state_dict(), load_calibration())
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(sd[k])
+    model.eval()
+    return model
+
+
+def make_icodec(weight_set="W0", calibrated=True):
+    """Product `ICIP2020ResB` (I-frame codec) on the CPU with the named synthetic weight set: seeded default init x the
+    multipliers of deepsvc_amd/data/icip_w0_calibration.json (tools/calibrate_icip.py)."""
+    from .image_model import ICIP2020ResB
+    seed = {"W0": 0, "W1": 1}[weight_set]
+    rng = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = ICIP2020ResB()
+    torch.random.set_rng_state(rng)
+    if calibrated:
+        sd = apply_calibration(model.state_dict(), load_calibration(ICIP_CALIBRATION))
         with torch.no_grad():
             for k, v in model.state_dict().items():
                 v.copy_(sd[k])
