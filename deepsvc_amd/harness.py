@@ -32,14 +32,27 @@ def _psnr(a, b):
     return 99.0 if mse <= 0 else -10.0 * math.log10(mse)
 
 
-def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True):
-    """Encode+decode one GOP.  frames[0] is the (already decoded) key frame, frames[1:] are P-frames; all are
-    [1,3,h,w] tensors on the model's device, un-padded.  Returns one metric row per P-frame."""
+def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=None):
+    """Encode+decode one GOP.  frames[1:] are P-frames; frames[0] is the key frame: taken as already decoded when
+    `i_model` is None (BASELINE.json configs 1-2), else coded with the I-frame codec `i_model` (`ICIP2020ResB`,
+    test_video.py:296-312: compress -> decompress, the clamped reconstruction becomes the first reference) and reported
+    as a row with frame index 0 whose `bpp_res` column holds the I-frame bpp.  All frames are [1,3,h,w] tensors on the
+    model's device, un-padded.  Returns one metric row per coded frame."""
     sync = sync or (lambda: None)
     h, w = frames[0].shape[-2:]
-    ref = pad(frames[0], 64)
-    feature = None
     rows = []
+    if i_model is None:
+        ref = pad(frames[0], 64)
+    else:
+        key = pad(frames[0], 64)
+        sync(); t0 = time.perf_counter()
+        i_enc = i_model.compress(key)
+        sync(); t1 = time.perf_counter()
+        ref = i_model.decompress(i_enc["strings"], i_enc["shape"])["x_hat"]
+        sync(); t2 = time.perf_counter()
+        i_psnr = _psnr(crop(ref, (h, w)), frames[0]) if metrics else 0.0
+        rows.append([float(unit), 0.0, 0.0, strings_bytes(i_enc) * 8.0 / (h * w), i_psnr, 0.0, 0.0, t1 - t0, t2 - t1])
+    feature = None
     for t in range(1, len(frames)):
         cur = pad(frames[t], 64)
         sm = sm_feas[t]

@@ -101,3 +101,24 @@ def test_icip_roundtrip_properties_large_and_bf16():
         assert psnr(xb, xf) > 30                         # 13 untrained 192-channel synthesis layers amplify bf16 rounding
     finally:
         ops.set_precision("fp32")
+
+
+def test_gop_with_intra_coded_key_frame():
+    """BASELINE.json config 3 plumbing on the GPU: I-frame codec for the key frame, its reconstruction as the reference
+    of the P-frame chain (harness.code_gop(..., i_model=...), test_video.py:296-312)."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("bf16")
+    try:
+        i_model = synth.make_icodec("W0"); i_model.update(force=True); i_model = i_model.to(DEV)
+        p_model = synth.make_model("W0"); p_model.update(force=True); p_model = p_model.to(DEV)
+        size = 128
+        frames = [f.to(DEV) for f in synth.make_frames(size, size, 4)]
+        sms = [None] + [synth.make_sm_fea(size, size, t).to(DEV) for t in (1, 2, 3)]
+        rows = harness.code_gop(p_model, frames, sms, unit=3, sync=torch.cuda.synchronize, i_model=i_model)
+        assert [r[1] for r in rows] == [0.0, 1.0, 2.0, 3.0]
+        assert rows[0][3] > 0.0 and all(r[2] > 0.0 and r[3] > 0.0 for r in rows[1:])
+        assert all(np.isfinite(r[4]) for r in rows)
+        table = harness.gather_rows(rows, torch.device(DEV), 1)
+        assert table.shape == (4, len(harness.METRIC_COLUMNS))
+    finally:
+        ops.set_precision("fp32")

@@ -52,6 +52,27 @@ def test_code_gop_chains_state_and_measures():
     assert codec.calls[2][1] < codec.calls[0][1]
 
 
+class _StubICodec:
+    def compress(self, x):
+        return {"strings": [[b"\x01" * 50], [b"\x02" * 5]], "shape": (1, 2)}
+
+    def decompress(self, strings, shape):
+        assert len(strings[0][0]) == 50 and tuple(shape) == (1, 2)
+        return {"x_hat": torch.full((1, 3, 64, 128), 0.4)}
+
+
+def test_code_gop_with_intra_coded_key_frame():
+    """BASELINE.json config 3 plumbing (test_video.py:296-312): the key frame goes through the I-frame codec, its clamped
+    reconstruction is the first reference, and it gets a row (frame 0) with its own bpp."""
+    frames = [torch.full((1, 3, 60, 100), 0.8) for _ in range(3)]
+    sms = [None] + [torch.zeros(1, 256, 16, 32) for _ in range(2)]
+    codec = _StubCodec()
+    rows = harness.code_gop(codec, frames, sms, unit=2, i_model=_StubICodec())
+    assert [r[1] for r in rows] == [0.0, 1.0, 2.0]
+    assert rows[0][2] == 0.0 and abs(rows[0][3] - 55 * 8 / 6000) < 1e-12
+    assert abs(codec.calls[0][1] - 0.4) < 1e-6          # the P-frame codec's first reference is the I-frame reconstruction
+
+
 WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[3])
