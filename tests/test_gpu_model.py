@@ -249,3 +249,21 @@ def test_full_size_1080p_roundtrip_properties(oracle_w0):
         psnr = 99.0 if mse == 0 else -10.0 * float(np.log10(mse))
         print(f"1080p frame {t}: fp32 {na} B, bf16 {nb} B ({100.0 * (nb - na) / na:+.3f} %), PSNR(bf16 recon, fp32 recon) = {psnr:.1f} dB")
         assert psnr > 40.0
+
+
+def test_frame_container_round_trip_on_gpu(model):
+    """Encoder output -> on-disk container bytes -> decoder: identical pictures, exact overhead."""
+    from deepsvc_amd import bitstream, ops, synth
+    ops.set_precision("fp32")
+    size = 128
+    fr = synth.make_frames(size, size, 2)
+    sm = synth.make_sm_fea(size, size, 1).to(DEV)
+    mv, res = model.compress(fr[0].to(DEV), fr[1].to(DEV), sm, None)
+    blob = bitstream.pack_frame(mv, res)
+    ftype, (mv2, res2) = bitstream.unpack_frame(blob)
+    assert ftype == bitstream.TYPE_P
+    payload = sum(len(s[0]) for e in (mv, res) for s in e["strings"])
+    assert len(blob) == payload + bitstream.frame_overhead_bytes(mv, res)
+    a = model.decompress(fr[0].to(DEV), mv, res, sm, None)
+    b = model.decompress(fr[0].to(DEV), mv2, res2, sm, None)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0].float(), b[0].float())
