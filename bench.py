@@ -181,7 +181,7 @@ def main():
     metric_rows = []
     for unit, t, bmv, bres, recon, cur in rows:
         mse = float(((recon - cur) ** 2).mean())
-        metric_rows.append([unit, t, bmv, bres, -10 * torch.log10(torch.tensor(mse)).item() if mse > 0 else 99.0, 0.0, 0.0, 0.0, 0.0])
+        metric_rows.append([unit, t, bmv, bres, -10 * torch.log10(torch.tensor(mse)).item() if mse > 0 else 99.0, 0.0, 0.0, 0.0, 0.0, 0.0])
     table = harness.gather_rows(metric_rows, dev, world)
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

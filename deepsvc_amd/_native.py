@@ -69,6 +69,10 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "dsvc_reduce_workspace_floats": (c_int64, []),
     "dsvc_reduce": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(Operand), POINTER(Operand), c_void_p, c_void_p]),
+    "dsvc_ssim_workspace_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "dsvc_ssim_level": (c_int, [c_void_p, POINTER(Operand), POINTER(Operand), c_int32, c_int32, c_int32, c_int32, c_float,
+                                c_void_p, c_void_p, c_void_p]),
+    "dsvc_avgpool2_pad": (c_int, [c_void_p, POINTER(Operand), c_void_p, c_int32, c_int32, c_int32, c_int32]),
     "dsvc_gc_quantize": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32,
                                  c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32]),
     "dsvc_gc_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32]),

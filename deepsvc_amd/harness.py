@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from .modules import crop, pad
 
-METRIC_COLUMNS = ("unit", "frame", "bpp_mv", "bpp_res", "psnr", "psnr_mc", "psnr_warp", "t_enc", "t_dec")
+METRIC_COLUMNS = ("unit", "frame", "bpp_mv", "bpp_res", "psnr", "psnr_mc", "psnr_warp", "t_enc", "t_dec", "msssim")
 
 
 def shard_units(n_units, rank, world_size):
@@ -32,12 +32,18 @@ def _psnr(a, b):
     return 99.0 if mse <= 0 else -10.0 * math.log10(mse)
 
 
-def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=None):
+def _msssim(a, b):
+    from .metrics import ms_ssim
+    return float(ms_ssim(a.contiguous(), b.contiguous(), 1.0))
+
+
+def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=None, msssim=False):
     """Encode+decode one GOP.  frames[1:] are P-frames; frames[0] is the key frame: taken as already decoded when
     `i_model` is None (BASELINE.json configs 1-2), else coded with the I-frame codec `i_model` (`ICIP2020ResB`,
     test_video.py:296-312: compress -> decompress, the clamped reconstruction becomes the first reference) and reported
     as a row with frame index 0 whose `bpp_res` column holds the I-frame bpp.  All frames are [1,3,h,w] tensors on the
-    model's device, un-padded.  Returns one metric row per coded frame."""
+    model's device, un-padded.  Returns one metric row per coded frame.  `msssim=True` fills the last column with MS-SSIM of
+    the cropped reconstruction (test_video.py:311,359-363; GPU kernel, frames must exceed 160 px on the smaller side)."""
     sync = sync or (lambda: None)
     h, w = frames[0].shape[-2:]
     rows = []
@@ -51,7 +57,8 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
         ref = i_model.decompress(i_enc["strings"], i_enc["shape"])["x_hat"]
         sync(); t2 = time.perf_counter()
         i_psnr = _psnr(crop(ref, (h, w)), frames[0]) if metrics else 0.0
-        rows.append([float(unit), 0.0, 0.0, strings_bytes(i_enc) * 8.0 / (h * w), i_psnr, 0.0, 0.0, t1 - t0, t2 - t1])
+        rows.append([float(unit), 0.0, 0.0, strings_bytes(i_enc) * 8.0 / (h * w), i_psnr, 0.0, 0.0, t1 - t0, t2 - t1,
+                     _msssim(crop(ref, (h, w)), frames[0]) if msssim else 0.0])
     feature = None
     for t in range(1, len(frames)):
         cur = pad(frames[t], 64)
@@ -67,7 +74,7 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
             row += [_psnr(crop(recon, (h, w)), org), _psnr(crop(predict, (h, w)), org), _psnr(crop(warped, (h, w)), org)]
         else:
             row += [0.0, 0.0, 0.0]
-        rows.append(row + [t1 - t0, t2 - t1])
+        rows.append(row + [t1 - t0, t2 - t1, _msssim(crop(recon, (h, w)), frames[t]) if msssim else 0.0])
         ref = recon
     return rows
 
@@ -95,4 +102,5 @@ def summarise(table):
             "mvbpp": float(cols["bpp_mv"].mean()) if n else 0.0, "resbpp": float(cols["bpp_res"].mean()) if n else 0.0,
             "ppsnr": float(cols["psnr"].mean()) if n else 0.0, "mcpsnr": float(cols["psnr_mc"].mean()) if n else 0.0,
             "warppsnr": float(cols["psnr_warp"].mean()) if n else 0.0,
-            "pent": float(cols["t_enc"].mean()) if n else 0.0, "pdec": float(cols["t_dec"].mean()) if n else 0.0}
+            "pent": float(cols["t_enc"].mean()) if n else 0.0, "pdec": float(cols["t_dec"].mean()) if n else 0.0,
+            "pmsssim": float(cols["msssim"].mean()) if n else 0.0}

@@ -333,6 +333,25 @@ def reduce(mode, a, b=None):
     return out
 
 
+def ssim_level(x, y, data_range=1.0):
+    """One MS-SSIM level -> (ssim[B*C], cs[B*C]) fp32 device vectors (include/dsvc.h: dsvc_ssim_level)."""
+    assert (x.B, x.H, x.W, x.C) == (y.B, y.H, y.W, y.C)
+    L = N.lib()
+    ws = torch.empty(max(L.dsvc_ssim_workspace_floats(x.B, x.H, x.W, x.C), 1), dtype=torch.float32, device=x.device)
+    out = torch.empty((2, x.B * x.C), dtype=torch.float32, device=x.device)
+    N.check(L.dsvc_ssim_level(_stream(), _op(x), _op(y), x.B, x.H, x.W, x.C, float(data_range), ws.data_ptr(),
+                              out[0].data_ptr(), out[1].data_ptr()), "ssim_level")
+    return out[0], out[1]
+
+
+def avgpool2_pad(x):
+    """F.avg_pool2d(x, 2, padding=(H % 2, W % 2)) -> dense fp32 Act."""
+    Ho, Wo = (x.H + 2 * (x.H & 1) - 2) // 2 + 1, (x.W + 2 * (x.W & 1) - 2) // 2 + 1
+    out = new_act(x.B, Ho, Wo, x.C, torch.float32, x.device)
+    N.check(N.lib().dsvc_avgpool2_pad(_stream(), _op(x), out.ptr, x.B, x.H, x.W, x.C), "avgpool2_pad")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # entropy-model device arithmetic
 # --------------------------------------------------------------------------------------------

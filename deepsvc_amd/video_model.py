@@ -114,9 +114,30 @@ class DeepSVC(nn.Module):
         return (predict.nchw(), (ops.reduce("sqdiff", warped, cur) / n).to(torch.float32),
                 (ops.reduce("sqdiff", predict, cur) / n).to(torch.float32), self._bpp([y_lik, z_lik], pixels))
 
-    def forward_msssim(self, *args, **kwargs):
-        raise NotImplementedError("forward_msssim (video_model.py:96-135) needs pytorch-msssim's MS-SSIM, which is a "
-                                  "harness metric outside the P-frame hot path (SURVEY.md section 8f-3)")
+    def _estimate(self, ref_frame, curr_frame, sm_fea, feature):
+        """The estimate graph shared by forward / forward_msssim (video_model.py:27-71 == 96-135 up to the distortion)."""
+        ref, cur = to_act(ref_frame), to_act(curr_frame)
+        pixels = cur.B * cur.H * cur.W
+        mv_est = self.opticFlow.run(cur, ref)
+        mv_coarse, y_lik, z_lik = self.mv_codec.run_forward([cur, mv_est, ref], x_hat_dtype=F32)
+        warped, warp_fea, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
+        bpp_mv = self._bpp([y_lik, z_lik], pixels)
+        predict_fea = self.FeatureExtractor.run(predict)
+        cur_fea = self.FeatureExtractor.run(cur)
+        res = ops.eltwise(N.EW_SUB, cur_fea, predict_fea)
+        res_coarse, y_lik, z_lik = self.res_codec.run_forward([ref, res, predict])
+        bpp_res = self._bpp([y_lik, z_lik], pixels)
+        feat, recon = self._reconstruct(ref, predict_fea, res_coarse, warp_fea)
+        return cur, warped, predict, feat, recon, bpp_res, bpp_mv
+
+    @torch.no_grad()
+    def forward_msssim(self, ref_frame, curr_frame, sm_fea, feature=None):
+        """video_model.py:96-135 -> (recon, feature, msssim, warp_msssim, mc_msssim, bpp_res, bpp_mv, bpp): the estimate
+        path with MS-SSIM (data_range 1.0; deepsvc_amd.metrics.ms_ssim, a HIP kernel per scale) in place of the MSEs."""
+        from .metrics import ms_ssim
+        cur, warped, predict, feat, recon, bpp_res, bpp_mv = self._estimate(ref_frame, curr_frame, sm_fea, feature)
+        return (recon.nchw(), feat.nchw(), ms_ssim(recon, cur, 1.0), ms_ssim(warped, cur, 1.0), ms_ssim(predict, cur, 1.0),
+                bpp_res, bpp_mv, bpp_mv + bpp_res)
 
     # ------------------------------------------------------------------------------------------
     # real bitstream path

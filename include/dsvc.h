@@ -153,6 +153,18 @@ int64_t dsvc_reduce_workspace_floats(void);
 int dsvc_reduce(void* stream, int32_t mode, int64_t n_pix, int32_t C, const dsvc_operand* a, const dsvc_operand* b,
                 float* partial, double* out);
 
+/* One level of MS-SSIM with pytorch-msssim 0.2.1 semantics (third-party, absent from the reference tree; call sites
+ * video_model.py:107,114,132 and test_video.py:311,359-363: ms_ssim(x, y, data_range=1.0)):
+ * out_ssim[b*C+c], out_cs[b*C+c] = mean over the VALID positions of the separable 11-tap Gaussian window (sigma 1.5)
+ * of the ssim / contrast-structure maps, K = (0.01, 0.03).  x, y: NHWC slices of either storage type, H, W >= 11.
+ * workspace: dsvc_ssim_workspace_floats(B,H,W,C) floats.  Deterministic (no atomics, fp64 final sum).
+ * dsvc_avgpool2_pad: F.avg_pool2d(x, 2, padding=(H%2, W%2)) between the levels (zeros count, divide by 4) into a dense
+ * fp32 NHWC tensor of size B x ((H+2(H%2)-2)/2+1) x ((W+2(W%2)-2)/2+1) x C. */
+int64_t dsvc_ssim_workspace_floats(int32_t B, int32_t H, int32_t W, int32_t C);
+int dsvc_ssim_level(void* stream, const dsvc_operand* x, const dsvc_operand* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                    float data_range, float* workspace, float* out_ssim, float* out_cs);
+int dsvc_avgpool2_pad(void* stream, const dsvc_operand* x, float* out, int32_t B, int32_t H, int32_t W, int32_t C);
+
 /* ------------------------------------------------------------------------------------------
  * Entropy-model arithmetic on device (compressai 1.2.1 semantics)
  * Symbol / index planes are int32 in the reference's NCHW flattening order [C][h][w]

@@ -111,10 +111,11 @@ def test_gop_with_intra_coded_key_frame():
     try:
         i_model = synth.make_icodec("W0"); i_model.update(force=True); i_model = i_model.to(DEV)
         p_model = synth.make_model("W0"); p_model.update(force=True); p_model = p_model.to(DEV)
-        size = 128
+        size = 192
         frames = [f.to(DEV) for f in synth.make_frames(size, size, 4)]
         sms = [None] + [synth.make_sm_fea(size, size, t).to(DEV) for t in (1, 2, 3)]
-        rows = harness.code_gop(p_model, frames, sms, unit=3, sync=torch.cuda.synchronize, i_model=i_model)
+        rows = harness.code_gop(p_model, frames, sms, unit=3, sync=torch.cuda.synchronize, i_model=i_model, msssim=True)
+        assert all(0.0 < r[9] <= 1.0 for r in rows)
         assert [r[1] for r in rows] == [0.0, 1.0, 2.0, 3.0]
         assert rows[0][3] > 0.0 and all(r[2] > 0.0 and r[3] > 0.0 for r in rows[1:])
         assert all(np.isfinite(r[4]) for r in rows)

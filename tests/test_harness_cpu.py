@@ -80,7 +80,7 @@ from deepsvc_amd import harness
 rank, world = int(sys.argv[1]), int(sys.argv[2])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 units = harness.shard_units(5, rank, world)          # 5 GOPs over 2 ranks: ranks get 3 and 2 -> ragged gather
-rows = [[float(u), float(t), 0.1 * u, 0.2, 30.0 + u, 0, 0, 0.01, 0.02] for u in units for t in (1, 2)]
+rows = [[float(u), float(t), 0.1 * u, 0.2, 30.0 + u, 0, 0, 0.01, 0.02, 0.9] for u in units for t in (1, 2)]
 table = harness.gather_rows(rows, torch.device("cpu"), world)
 assert table.shape == (10, len(harness.METRIC_COLUMNS)), table.shape
 assert sorted(set(table[:, 0].tolist())) == [0.0, 1.0, 2.0, 3.0, 4.0]
