@@ -267,3 +267,59 @@ def test_frame_container_round_trip_on_gpu(model):
     a = model.decompress(fr[0].to(DEV), mv, res, sm, None)
     b = model.decompress(fr[0].to(DEV), mv2, res2, sm, None)
     assert torch.equal(a[1], b[1]) and torch.equal(a[0].float(), b[0].float())
+
+
+def test_w1_weight_set_parity(oracle_w0):
+    """BASELINE.json config 4's "MS-SSIM model" is the same code path with another weight set: W1 (seed 1) through the
+    real bitstream path in fp32 mode against the oracle on the same weights -- bytes within 1 %, PSNR within 0.05 dB."""
+    from deepsvc_amd import ops, synth
+    from oracle.codec import DeepSVCOracle, strings_nbytes
+    ops.set_precision("fp32")
+    m = synth.make_model("W1")
+    m.update(force=True)
+    orc = DeepSVCOracle(m.state_dict())
+    orc.update(force=True)
+    m = m.to(DEV)
+    size = 64
+    fr = synth.make_frames(size, size, 2)
+    sm = synth.make_sm_fea(size, size, 1)
+    mv_g, res_g = m.compress(fr[0].to(DEV), fr[1].to(DEV), sm.to(DEV), None)
+    dec_g = m.decompress(fr[0].to(DEV), mv_g, res_g, sm.to(DEV), None)
+    mv_o, res_o = orc.compress(fr[0], fr[1], sm, None)
+    dec_o = orc.decompress(fr[0], mv_o, res_o, sm, None)
+    bg, bo = strings_nbytes(mv_g) + strings_nbytes(res_g), strings_nbytes(mv_o) + strings_nbytes(res_o)
+    print(f"W1 64x64: bytes gpu {bg} oracle {bo}; identical y strings: mv {mv_g['strings'][0][0] == mv_o['strings'][0][0]}, "
+          f"res {res_g['strings'][0][0] == res_o['strings'][0][0]}")
+    assert abs(bg - bo) <= max(0.01 * bo, 8)
+    assert abs(psnr(dec_g[1].cpu(), fr[1]) - psnr(dec_o[1], fr[1])) <= 0.05
+    assert psnr(dec_g[1].cpu(), dec_o[1]) > 40
+
+
+def test_4k_whole_frame_round_trip_bf16():
+    """BASELINE.json config 5 size (3840x2160 -> padded 2176x3840) as a whole frame on one GPU in bf16 mode (DESIGN.md
+    section 6: spatial tiling is not result-preserving, so 4K runs un-tiled): the encode -> decode round trip holds
+    (decoder latents == encoder latents), decoding is deterministic, every buffer stays under the 2 GiB extent limit."""
+    from deepsvc_amd import ops, synth
+    from deepsvc_amd.modules import pad
+    ops.set_precision("bf16")
+    try:
+        m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+        frames = [pad(f.to(DEV), 64) for f in synth.make_frames(2160, 3840, 2, seed=3)]
+        assert tuple(frames[0].shape[-2:]) == (2176, 3840)
+        sm = synth.make_sm_fea(2176, 3840, 1, seed=3).to(DEV)
+        mv, res = m.compress(frames[0], frames[1], sm, None)
+        mv, res = {k: mv[k] for k in ("strings", "shape")}, {k: res[k] for k in ("strings", "shape")}
+        torch.cuda.synchronize()
+        dev = torch.device(DEV)
+        enc_lat = [c._plan(1, 136, 240, dev).y_hat.buf.clone() for c in (m.mv_codec, m.res_codec)]
+        f1, r1, _, _ = m.decompress(frames[0], mv, res, sm, None)
+        torch.cuda.synchronize()
+        dec_lat = [c._plan(1, 136, 240, dev).y_hat.buf.clone() for c in (m.mv_codec, m.res_codec)]
+        f2, r2, _, _ = m.decompress(frames[0], mv, res, sm, None)
+        assert all(torch.equal(a, b) for a, b in zip(enc_lat, dec_lat))
+        assert torch.equal(r1, r2) and torch.equal(f1.float(), f2.float())
+        nbytes = sum(len(s[0]) for e in (mv, res) for s in e["strings"])
+        print(f"4K frame: {nbytes} B = {nbytes * 8 / (2160 * 3840):.3f} bpp, peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+        assert tuple(mv["shape"]) == (34, 60) and torch.isfinite(r1).all()
+    finally:
+        ops.set_precision("fp32")
