@@ -117,11 +117,6 @@ def test_forward_matches_oracle_and_reference_golden(model, oracle_w0, golden64,
     assert d_psnr <= 0.05, f"|dPSNR| = {d_psnr:.4f} dB"
 
 
-def _symbols_of(codec_mod, strings, shape, n_ch):
-    """Decode a y-string back to symbols using the product's host coder with indexes recomputed on the GPU."""
-    return None
-
-
 @pytest.mark.parametrize("size", [64, 128])
 def test_compress_decompress_roundtrip_and_parity(model, oracle_w0, size):
     from deepsvc_amd import synth
