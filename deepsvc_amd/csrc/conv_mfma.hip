@@ -390,8 +390,11 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
         return (int64_t)p.B * ((p.Ho + 4 * mt - 1) / (4 * mt)) * ((p.Wo + TW - 1) / TW) * ((ntiles32 + nt - 1) / nt);
     };
     // small problems (entropy-parameter nets at 1/16 res): trade operand reuse for more workgroups
-    if (nblocks(MT, NT) < 512 && MT == 2) MT = 1;
-    while (nblocks(MT, NT) < 512 && NT > 1) NT = (NT + 1) / 2;
+    // 400, not 512: at 1/4 resolution (272x480) the 8x32 tiling gives 510 workgroups -- two per CU, which is fine -- and
+    // halves the weight re-staging per pixel (128->128 3x3: 90 -> 70 us); below ~1.5 workgroups per CU go finer
+    static const int mt_thr = getenv("DSVC_MT_THR") ? atoi(getenv("DSVC_MT_THR")) : 400;
+    if (nblocks(MT, NT) < mt_thr && MT == 2) MT = 1;
+    while (nblocks(MT, NT) < mt_thr && NT > 1) NT = (NT + 1) / 2;
     const int TH = 4 * MT;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
