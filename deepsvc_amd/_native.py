@@ -33,6 +33,7 @@ class ConvDesc(Structure):
         ("res2", c_void_p), ("res2_ld", c_int32), ("res2_dtype", c_int32),
         ("shuffle", c_int32),
         ("out", c_void_p), ("out_ld", c_int32), ("out_dtype", c_int32),
+        ("s2d", c_int32),
     ]
 
 

@@ -29,6 +29,7 @@ struct ConvParams {
     int tiles_x, tiles_y, tapg;
     unsigned out_bytes, res1_bytes, res2_bytes;   // extents for the buffer resources of the vector epilogue
     int epi_vec;                                   // 1: epilogue may use 4-channel vector buffer ops everywhere
+    int s2d;                                       // 1: inputs are a space-to-depth view of a (2H x 2W) image (dsvc.h)
 };
 
 // ---- raw buffer resources: hardware bounds checking instead of branches ------------------------------------------

@@ -96,7 +96,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             constexpr int PB = 6;
             const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);      // out-of-image pixels read as zeros (bounds-checked loads)
             const unsigned pitch = (unsigned)sg.ld * sizeof(CT);
-            const unsigned img = (unsigned)b * p.H * p.W * pitch + c0 * (unsigned)sizeof(CT) + q * 16;
+            // plain: quarter q = channels c0 + q*EPV of the pixel.  space-to-depth view: quarter q = image pixel
+            // (2Y + q/2, 2X + q%2), channels (chunk index in the segment) * EPV .. of a (2H x 2W) image
+            const unsigned img = p.s2d ? (unsigned)b * 4u * p.H * p.W * pitch + (unsigned)(ch - sg.chunk0) * 16u +
+                                             ((unsigned)(q >> 1) * 2u * p.W + (unsigned)(q & 1)) * pitch
+                                       : (unsigned)b * p.H * p.W * pitch + c0 * (unsigned)sizeof(CT) + q * 16;
+            const unsigned pixstep = p.s2d ? 2u : 1u, rowstep = p.s2d ? 4u * p.W : (unsigned)p.W;
             const bool qvalid = c0 + q * EPV < sg.C;           // a short last chunk: the missing 16-B quarters read as zeros
             int py = py0, px = px0;
             for (int base = pix0; base < npatch; base += 64 * PB) {
@@ -107,7 +112,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     const int iy = iy0 + py, ix = ix0 + px;
                     lr[j] = lds_row(py, px);
                     const bool inb = qvalid && base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    v[j] = buf_load16(rs, inb ? img + ((unsigned)iy * p.W + ix) * pitch : OOB);
+                    v[j] = buf_load16(rs, inb ? img + ((unsigned)iy * rowstep + (unsigned)ix * pixstep) * pitch : OOB);
                     px += dpx; py += dpy;
                     if (px >= PW) { px -= PW; ++py; }
                 }
@@ -321,10 +326,15 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     int chunk0 = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const dsvc_seg& in = d->in[s];
-        DSVC_REQUIRE(in.ptr && in.C > 0 && in.ld >= in.C, "conv2d: segment %d ptr/C/ld invalid (C=%d ld=%d)", s, in.C, in.ld);
+        DSVC_REQUIRE(in.ptr && in.C > 0 && in.ld >= (d->s2d ? in.C / 4 : in.C), "conv2d: segment %d ptr/C/ld invalid (C=%d ld=%d)", s, in.C, in.ld);
         DSVC_REQUIRE(in.dtype == DSVC_F32 || in.dtype == DSVC_BF16, "conv2d: segment %d dtype", s);
         const int es = dsvc_esize(in.dtype);
-        const int64_t ext = (((int64_t)d->B * d->H * d->W - 1) * in.ld + in.C) * es;
+        if (d->s2d)
+            DSVC_REQUIRE(in.dtype == d->compute && in.C % kce == 0 && ((uintptr_t)in.ptr & 15) == 0 && ((int64_t)in.ld * es) % 16 == 0,
+                         "conv2d: s2d segment %d needs storage == compute type, C %% %d == 0 and 16-byte aligned rows", s, kce);
+        // extent of the underlying image: the view grid itself, or the (2H x 2W) image behind a space-to-depth view
+        const int64_t ext = d->s2d ? (((int64_t)d->B * 4 * d->H * d->W - 1) * in.ld + in.C / 4) * es
+                                   : (((int64_t)d->B * d->H * d->W - 1) * in.ld + in.C) * es;
         DSVC_REQUIRE(ext < 0x7FFFFFF0ll, "conv2d: input segment %d spans %lld bytes (limit 2 GiB)", s, (long long)ext);
         p.seg[s] = ConvSeg{in.ptr, in.C, in.ld, in.dtype,
                            (int)((((uintptr_t)in.ptr & 15) == 0) && (((int64_t)in.ld * es) % 16 == 0)), chunk0, (unsigned)ext};
@@ -332,6 +342,8 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     }
     p.nseg = d->nseg; p.nchunks = chunk0;
     p.B = d->B; p.H = d->H; p.W = d->W;
+    p.s2d = d->s2d ? 1 : 0;
+    DSVC_REQUIRE(!d->s2d || (d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1), "conv2d: s2d needs a 3x3 stride-1 pad-1 kernel");
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
     p.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
     p.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
@@ -365,7 +377,11 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
         fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == d->compute && (p.seg[s].C % (kce / 4)) == 0;
 
     // ---- bf16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
-    const DsvcOptions& opt = g_dsvc_opt;
+    DsvcOptions opt = g_dsvc_opt;
+    if (p.s2d) {                            // only the general kernel's staging understands the space-to-depth view
+        DSVC_REQUIRE(fast, "conv2d: s2d needs the vector staging path");
+        opt.specialised = 0;
+    }
     if (opt.specialised && opt.direct) {    // small images (entropy-scan nets): barrier-free kernel, fragments straight from L2
         const int rc = dsvc_conv3x3_direct_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;             // 1 = not applicable, try the next kernel

@@ -33,15 +33,28 @@ def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
 class Conv2d(nn.Conv2d):
     """nn.Conv2d parameters (same keys) executed by the fused MFMA conv kernel."""
 
-    def _packed(self, seg_channels, device, phys_channels=None):
+    def _packed(self, seg_channels, device, phys_channels=None, s2d=False):
         key = (tuple(seg_channels), None if phys_channels is None else tuple(phys_channels), ops.RT.compute, str(device),
-               self.weight._version, -1 if self.bias is None else self.bias._version, self.weight.data_ptr())
+               self.weight._version, -1 if self.bias is None else self.bias._version, self.weight.data_ptr(), s2d)
         cache = self.__dict__.setdefault("_pack_cache", {})
         if key not in cache:
             cache.clear()
             cache[key] = ops.PackedConv(self.weight, self.bias, seg_channels, self.stride[0], self.padding[0],
-                                        ops.RT.compute, device, phys_channels)
+                                        ops.RT.compute, device, phys_channels, s2d=s2d)
         return cache[key]
+
+    def _s2d_ok(self, phys_inputs):
+        """bf16 mode: conv5x5/s2 runs as a 3x3/s1 conv over the space-to-depth view of its inputs (include/dsvc.h: s2d) when
+        every input is bf16 with 16-byte pixel rows: no 25-tap weight re-staging per tile, and 8-channel segments fill a
+        32-channel chunk exactly (8 channels x 4 phases) instead of being padded to it."""
+        if not (ops.S2D[0] and ops.RT.compute == N.BF16 and self.kernel_size == (5, 5) and self.stride == (2, 2) and self.padding == (2, 2)
+                and all(a.dtype == torch.bfloat16 and a.C % 8 == 0 and a.ld % 8 == 0 and a.ptr % 16 == 0 and a.H % 2 == 0 and a.W % 2 == 0
+                        for a in phys_inputs)):
+            return False
+        # the view executes 36 MACs per input channel (9 taps x 4 phases, 11 of the 36 are structural zeros), the direct
+        # form 25 per channel of every 32-channel chunk it touches: the view wins for the first-layer convs whose 8-channel
+        # segments would be padded to full chunks (8+64+8 -> 96: 952 -> 632 us), not for 64/96-channel inputs (measured)
+        return 36 * sum(a.C for a in phys_inputs) <= 25 * sum(-(-a.C // 32) * 32 for a in phys_inputs)
 
     def _pack_small_runs(self, inputs):
         """bf16 mode: maximal runs of small fp32 inputs (frames, flows: 2-3 channels each) are merged into one bf16
@@ -81,8 +94,8 @@ class Conv2d(nn.Conv2d):
         if ops.RT.compute == N.BF16 and any(a.dtype == torch.float32 and a.C % 8 != 0 and a.C < 32 for a in inputs):
             phys, logical, physical = self._pack_small_runs(inputs)
             if len(phys) <= 3:
-                return ops.conv2d(self._packed(logical, phys[0].device, physical), phys, out, **epilogue)
-        return ops.conv2d(self._packed([a.C for a in inputs], inputs[0].device), inputs, out, **epilogue)
+                return ops.conv2d(self._packed(logical, phys[0].device, physical, s2d=self._s2d_ok(phys)), phys, out, **epilogue)
+        return ops.conv2d(self._packed([a.C for a in inputs], inputs[0].device, s2d=self._s2d_ok(inputs)), inputs, out, **epilogue)
 
     def forward(self, x):
         return self.run(to_act(x)).nchw()

@@ -57,6 +57,7 @@ def _stream():
 import threading as _threading
 
 _fork_pools = _threading.local()
+S2D = [_os.environ.get("DSVC_NO_S2D", "") == ""]       # conv5x5/s2 through the space-to-depth view (bf16 mode)
 USE_FORKS = [_os.environ.get("DSVC_FORKS", "") != ""]   # opt-in: measured 17.15 vs 17.6 fps (event edges cost more than the overlap)
 
 
@@ -172,7 +173,7 @@ def to_act(x, dtype=None):
 class PackedConv:
     """Device-resident packed weights (+ fp32 bias) of one conv for one (segments, compute type)."""
 
-    def __init__(self, w_oihw, bias, seg_channels, stride, pad, compute, device, phys_channels=None):
+    def __init__(self, w_oihw, bias, seg_channels, stride, pad, compute, device, phys_channels=None, s2d=False):
         """seg_channels: how the weight's input channels split over the input segments (torch.cat order);
         phys_channels: channels each segment physically provides (>= logical; the extra ones are zero padding of a
         packed buffer) -- the weight gets zero columns there."""
@@ -189,6 +190,12 @@ class PackedConv:
                 c += lc
             w = torch.cat(parts, 1).contiguous()
             seg_channels = phys_channels
+        self.s2d = bool(s2d)
+        if self.s2d:                         # conv5x5/s2 -> 3x3/s1 over the space-to-depth view (include/dsvc.h: s2d)
+            assert (self.kh, self.kw, stride, pad) == (5, 5, 2, 2)
+            w, seg_channels = s2d_weights(w, seg_channels, 8 if compute == N.BF16 else 4)
+            self.kh = self.kw = 3
+            stride, pad = 1, 1
         self.segC = tuple(int(c) for c in seg_channels)
         self.stride, self.pad, self.compute = stride, pad, compute
         segs = (ctypes.c_int32 * len(self.segC))(*self.segC)
@@ -201,6 +208,29 @@ class PackedConv:
         self.weight = torch.from_numpy(host).to(device)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
         PACK_EPOCH[0] += 1
+
+
+def s2d_weights(w5, seg_channels, V):
+    """[Cout, Cin, 5, 5] weights of a stride-2 pad-2 conv -> [Cout, 4*Cin, 3, 3] weights of the equivalent stride-1 pad-1
+    conv over the space-to-depth view of include/dsvc.h (view channel g*4V + (2*py+px)*V + c = channel g*V + c of image
+    pixel (2Y+py, 2X+px), per input segment):  out(y,x) = sum W5[ky][kx] in[2y+ky-2][2x+kx-2], and 2y + ky - 2 =
+    2(y+dy) + py with ky = 2*dy + py + 2, so W3[.., dy+1, dx+1] at phase (py,px) = W5[.., 2dy+py+2, 2dx+px+2] (absent taps 0)."""
+    cout = w5.shape[0]
+    parts, c0 = [], 0
+    for C in seg_channels:
+        assert C % V == 0, f"s2d needs segment channels % {V} == 0, got {C}"
+        ws = w5[:, c0:c0 + C]                                        # [Cout, C, 5, 5]
+        w3 = torch.zeros((cout, C // V, 4, V, 3, 3), dtype=torch.float32)
+        for py in range(2):
+            for px in range(2):
+                for dy in range(-1, 2):
+                    for dx in range(-1, 2):
+                        ky, kx = 2 * dy + py + 2, 2 * dx + px + 2
+                        if 0 <= ky < 5 and 0 <= kx < 5:
+                            w3[:, :, 2 * py + px, :, dy + 1, dx + 1] = ws[:, :, ky, kx].reshape(cout, C // V, V)
+        parts.append(w3.reshape(cout, 4 * C, 3, 3))
+        c0 += C
+    return torch.cat(parts, 1).contiguous(), [4 * C for C in seg_channels]
 
 
 def deconv_as_conv_weights(w_iohw, bias):
@@ -226,8 +256,15 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
     """Run one fused conv.  inputs: list of Act (virtual torch.cat along channels)."""
     x0 = inputs[0]
     _require_gpu(x0.buf)
-    assert tuple(a.C for a in inputs) == pc.segC, f"input channels {[a.C for a in inputs]} != packed segments {pc.segC}"
+    s2d = getattr(pc, "s2d", False)
+    mult = 4 if s2d else 1
+    assert tuple(a.C * mult for a in inputs) == pc.segC, f"input channels {[a.C for a in inputs]} != packed segments {pc.segC}"
     B, H, W = x0.B, x0.H, x0.W
+    if s2d:                                 # the conv sees the (H/2 x W/2) space-to-depth view of the inputs
+        assert H % 2 == 0 and W % 2 == 0
+        for a in inputs:
+            assert (a.B, a.H, a.W) == (B, H, W)
+        H, W = H // 2, W // 2
     Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
     Wo = (W + 2 * pc.pad - pc.kw) // pc.stride + 1
     if out is None:
@@ -238,8 +275,9 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
     d = N.ConvDesc()
     d.B, d.H, d.W, d.nseg = B, H, W, len(inputs)
     for i, a in enumerate(inputs):
-        assert (a.B, a.H, a.W) == (B, H, W)
-        d.seg[i].ptr, d.seg[i].C, d.seg[i].ld, d.seg[i].dtype = a.ptr, a.C, a.ld, a.code
+        assert s2d or (a.B, a.H, a.W) == (B, H, W)
+        d.seg[i].ptr, d.seg[i].C, d.seg[i].ld, d.seg[i].dtype = a.ptr, a.C * mult, a.ld, a.code
+    d.s2d = 1 if s2d else 0
     d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, pc.stride, pc.pad
     d.Cout, d.compute = pc.Cout, pc.compute
     d.weight = pc.weight.data_ptr()

@@ -88,6 +88,14 @@ typedef struct dsvc_conv_desc {
     const void* res2; int32_t res2_ld, res2_dtype;
     int32_t shuffle;      /* 1, or r=2: nn.PixelShuffle(2) folded into the store (Cout % 4 == 0) */
     void* out; int32_t out_ld, out_dtype;
+    /* s2d = 1: the inputs are read through a SPACE-TO-DEPTH view: B, H, W describe the view grid, every view pixel (Y, X)
+     * is the 2x2 block of pixels (2Y+py, 2X+px) of a (2H x 2W) NHWC image with row pitch in[s].ld, and view channel
+     * g*4*V + (2*py+px)*V + c is channel g*V + c of that pixel (V = 8 for bf16 compute, 4 for fp32: one 16-byte vector).
+     * in[s].C counts VIEW channels (4x the image's).  Requires kh = kw = 3, stride 1, pad 1, input storage == compute type,
+     * 16-byte aligned rows.  This is how conv5x5/s2 (compressai conv(), image_model.py:53-66,344-358,376-382) runs: the
+     * 5x5 stride-2 kernel is exactly a 3x3 stride-1 kernel over this view (weights remapped once on the host), which
+     * avoids both the 25-tap weight re-staging per tile and the padding of 8-channel segments to 32-channel chunks. */
+    int32_t s2d;
 } dsvc_conv_desc;
 
 /* bytes of the packed weight buffer for a conv with these input segments */

@@ -273,6 +273,38 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
     report_close("direct vs torch", got, want, 2e-2 if out_dt == "bf16" else 5e-3, tol)
 
 
+@pytest.mark.parametrize("segs,cout,B,H,W", [((8, 64, 8), 96, 1, 64, 96), ((8,), 64, 2, 128, 160), ((8, 64, 8), 96, 1, 272, 480),
+                                             ((16, 8), 192, 1, 34, 62), ((8,), 192, 1, 64, 64)])
+def test_conv5x5s2_space_to_depth_view(segs, cout, B, H, W):
+    """bf16 conv5x5/s2 with bf16 inputs runs as a 3x3/s1 conv over the space-to-depth view (include/dsvc.h: s2d; weights
+    remapped by ops.s2d_weights): against torch's stride-2 conv on the same bf16-rounded operands, and against the
+    direct 5x5/s2 execution of the same layer."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout)
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(sum(segs), cout, 5, 2, 2).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        ins = [_act(x, bf) for x in xs]
+        assert m._s2d_ok(ins) and not Conv2d(96, 96, 5, 2, 2)._s2d_ok([_act(torch.zeros(1, 96, 8, 8), bf)])
+        got = m.run(ins, out_dtype=torch.float32).nchw().cpu()
+        ops.S2D[0] = False
+        try:
+            direct = m.run(ins, out_dtype=torch.float32).nchw().cpu()
+        finally:
+            ops.S2D[0] = True
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    want = F.conv2d(torch.cat([x.to(bf).float() for x in xs], 1), w, b, stride=2, padding=2)
+    assert got.shape == want.shape == (B, cout, H // 2, W // 2)
+    tol = 5e-3 * float(want.abs().max())
+    report_close("s2d vs torch", got, want, 5e-3, tol)
+    report_close("s2d vs direct 5x5/s2", got, direct, 5e-3, tol)
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
 def test_conv1x1_streaming_kernel(cin, cout):
     """Large bf16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,
