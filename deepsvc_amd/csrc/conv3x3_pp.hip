@@ -384,7 +384,8 @@ int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, 
         attr_set = true;
     }
     int grid = (ntiles + 1) / 2;
-    if (grid > 256) grid = 256;                                  // one persistent workgroup per CU, two tiles in flight each
+    static const int grid_cap = getenv("DSVC_PP_GRID") ? atoi(getenv("DSVC_PP_GRID")) : 256;
+    if (grid > grid_cap) grid = grid_cap;                        // one persistent workgroup per CU, two tiles in flight each
     const int nband = grid % 8 == 0 ? 8 : 1, band_tiles = (ntiles + nband - 1) / nband;   // as in the kernel
     const int iters = (band_tiles + 2 * (grid / nband) - 1) / (2 * (grid / nband));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, ntiles, iters, act_slope, pre_slope);
