@@ -34,6 +34,7 @@ class ConvDesc(Structure):
         ("shuffle", c_int32),
         ("out", c_void_p), ("out_ld", c_int32), ("out_dtype", c_int32),
         ("s2d", c_int32),
+        ("post_weight", c_void_p), ("post_bias", c_void_p),
     ]
 
 

@@ -75,7 +75,11 @@ __device__ __forceinline__ uint4 act_bf16x8(uint4 val, float slope) {
 // NCH: 32-channel input chunks (2: the schedule above; 1: inputs of <= 32 channels, phases M0 | E+S0 only).
 // HEAD: narrow output head (Cout <= 8, any activation, fp32 or bf16 out, optional residual of either type): one N-tile
 // is computed and the lanes that hold channels 0..7 store them element-wise.
-template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
+// POST: a 1x1 conv NT*32 -> NT*32 (ResBottleneckBlock.conv3) runs on the activated tile before the residual and the store: after
+// the first swap level lane (r, h) holds, as packed bf16, channels 16*kb + 8h .. +7 of pixel r for kb = 0..3 -- exactly the
+// B-operand fragment of k-block kb of a 32x32x16 MFMA -- so the tile feeds 2 x 4 MFMAs per row against weight fragments
+// read from LDS and the intermediate never leaves registers (it is rounded to bf16 as a stored tensor would be).
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
                                                               float pre_slope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,7 +94,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
     const int r = lane & 31, h = lane >> 5;
     char* lds_w = smem;                                                       // [chunk 2][tap 9][NTN] rows of 80 B
     char* lds_a = smem + NCH * 9 * NTN * ROWB + g * (PP_NPATCH * ROWB);        // this group's patch
-    float* lds_bias = (float*)(smem + NCH * 9 * NTN * ROWB + 2 * PP_NPATCH * ROWB);   // NTN floats
+    float* lds_bias = (float*)(smem + NCH * 9 * NTN * ROWB + 2 * PP_NPATCH * ROWB);   // NTN floats (+ NTN of the 1x1's bias)
+    char* lds_w3 = (char*)(lds_bias + 2 * NTN);                                        // POST: [chunk NT][NTN] rows of 80 B
     const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
     const rsrc_t rr1 = make_rsrc(HAS_R1 ? p.res1 : p.out, HAS_R1 ? p.res1_bytes : p.out_bytes);
     const rsrc_t rr2 = make_rsrc(HAS_R2 ? p.res2 : p.out, HAS_R2 ? p.res2_bytes : p.out_bytes);
@@ -113,6 +118,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
     }
 
     if (tid < NTN) lds_bias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
+    if constexpr (POST) {
+        if (tid < NTN) lds_bias[NTN + tid] = (p.post_bias && tid < p.Cout) ? p.post_bias[tid] : 0.f;
+        const int q4 = tid & 3;                     // packed 1x1 weights: [chunk][tap 0][Np == NTN] rows of 64 B
+        for (int row = tid >> 2; row < NT * NTN; row += 128)
+            *(uint4*)(lds_w3 + row * ROWB + q4 * 16) = *(const uint4*)((const char*)p.post_w + (size_t)row * 64 + q4 * 16);
+    }
     const int H = p.H, W = p.W, tiles_x = p.tiles_x, tiles_y = p.tiles_y;
     // Address arithmetic is kept off the vector ALU as far as possible (it runs beside the other group's MFMA phase):
     // tile coordinates are wave-uniform and computed once per iteration; per-thread patch offsets are loop-invariant;
@@ -329,7 +340,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
             SWAP32(acc[M][N][j], acc[M][N][4 + j], v0[j], v0[4 + j])                                                \
             SWAP32(acc[M][N][8 + j], acc[M][N][12 + j], v1[j], v1[4 + j])                                           \
         }                                                                                                           \
-        if constexpr (ACT) {                                                                                        \
+        if constexpr (ACT && !POST) {                                                                               \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) { v0[j] = lrelu_f(v0[j], act_slope); v1[j] = lrelu_f(v1[j], act_slope); } \
         }                                                                                                           \
         if constexpr (HAS_R1) {                                                                                     \
@@ -358,6 +369,39 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
         buf_store16(rout, o_out[M][0] + 64 * N, make_uint4(s0[0], s0[1], s0[2], s0[3]));                            \
         buf_store16(rout, o_out[M][1] + 64 * N, make_uint4(s1[0], s1[1], s1[2], s1[3]));                            \
     }
+            if constexpr (POST) {
+                static_assert(!POST || NT == 2, "fused 1x1: 64 -> 64 channels");
+#define PP_POST_ROW(M)                                                                                              \
+    {                                                                                                               \
+        unsigned bfr[4][4];          /* B fragments of k-blocks 0..3: act(conv3x3 + bias) of pixel r, packed bf16 */    \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                               \
+            _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                         \
+                float v[8];                                                                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+                    const float xq = acc[M][n][8 * P + j], yq = acc[M][n][8 * P + 4 + j];                           \
+                    const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false); \
+                    const unsigned lo_ = sw.x, hi_ = sw.y;                                                          \
+                    v[j] = __builtin_bit_cast(float, lo_); v[4 + j] = __builtin_bit_cast(float, hi_);               \
+                }                                                                                                   \
+                if constexpr (ACT) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = lrelu_f(v[j], act_slope); } \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) bfr[2 * n + P][d] = pk_bf16(v[2 * d], v[2 * d + 1]);    \
+            }                                                                                                       \
+        _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) {     /* accumulators of the 1x1 start as its bias */        \
+            _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {                                                      \
+                const float4 bq = *(const float4*)(lds_bias + NTN + n2 * 32 + 8 * qd + 4 * h);                      \
+                acc[M][n2][4 * qd] = bq.x; acc[M][n2][4 * qd + 1] = bq.y; acc[M][n2][4 * qd + 2] = bq.z; acc[M][n2][4 * qd + 3] = bq.w; \
+            }                                                                                                       \
+        }                                                                                                           \
+        _Pragma("unroll") for (int kb = 0; kb < 4; ++kb)                                                            \
+            _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) {                                                      \
+                const uint4 wf = *(const uint4*)(lds_w3 + ((kb >> 1) * NTN + n2 * 32 + r) * ROWB + (kb & 1) * 32 + h * 16); \
+                const uint4 bf4 = make_uint4(bfr[kb][0], bfr[kb][1], bfr[kb][2], bfr[kb][3]);                       \
+                acc[M][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, bf4), acc[M][n2], 0, 0, 0); \
+            }                                                                                                       \
+    }
+                PP_POST_ROW(0) PP_POST_ROW(1)
+#undef PP_POST_ROW
+            }
             PP_TILE(0, 0) PP_TILE(0, 1) PP_TILE(1, 0) PP_TILE(1, 1)
 #undef PP_TILE
 #undef SWAP16
@@ -373,11 +417,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
     if (!g) lds_barrier();               // matches group 1's leading barrier
 }
 
-template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2>
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false>
 int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, float pre_slope) {
-    const size_t lds = (size_t)NCH * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)NT * 32 * sizeof(float);
+    const size_t lds = (size_t)NCH * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)2 * NT * 32 * sizeof(float) +
+                       (POST ? (size_t)NT * NT * 32 * ROWB : 0);
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2>;
+    auto kern = conv3x3_pp_kernel<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
@@ -432,6 +477,17 @@ int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;   // pixel indices go through the 24-bit multiplier
     if (ntiles < 1024) return 1;           // small images: the generic kernel's finer tiling fills the chip better
+    if (d->post_weight) {                  // fused ResBottleneck tail: conv3x3 -> act -> conv1x1 -> + residual
+        float a_slope;
+        if (p.nchunks != 2 || d->Cout != 64 || d->pre_act != DSVC_ACT_NONE || d->res2 || !slope_of(d->act, d->slope, &a_slope)) return 1;
+        if (d->out_dtype != DSVC_BF16 || !vec16_ok(d->out, d->out_ld) || ((uintptr_t)d->post_weight & 15) != 0) return 1;
+        if (d->res1 && (d->res1_dtype != DSVC_BF16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
+        const bool act1 = d->act != DSVC_ACT_NONE;
+        if (d->res1) return act1 ? launch_pp<2, 2, false, false, true, true, false, true>(st, p, ntiles, a_slope, 1.f)
+                                 : launch_pp<2, 2, false, false, false, true, false, true>(st, p, ntiles, 1.f, 1.f);
+        return act1 ? launch_pp<2, 2, false, false, true, false, false, true>(st, p, ntiles, a_slope, 1.f)
+                    : launch_pp<2, 2, false, false, false, false, false, true>(st, p, ntiles, 1.f, 1.f);
+    }
     if (d->Cout <= 8) {                    // narrow heads (flow / frame / mask outputs): any activation, element-wise stores
         if (d->pre_act != DSVC_ACT_NONE || d->res2) return 1;
         return p.nchunks == 2 ? launch_pp<1, 2, true, false, false, false, false>(st, p, ntiles, 1.f, 1.f)

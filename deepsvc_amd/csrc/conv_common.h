@@ -30,6 +30,7 @@ struct ConvParams {
     unsigned out_bytes, res1_bytes, res2_bytes;   // extents for the buffer resources of the vector epilogue
     int epi_vec;                                   // 1: epilogue may use 4-channel vector buffer ops everywhere
     int s2d;                                       // 1: inputs are a space-to-depth view of a (2H x 2W) image (dsvc.h)
+    const void* post_w; const float* post_bias;    // fused trailing 1x1 conv (dsvc.h: post_weight), conv3x3_pp only
 };
 
 // ---- raw buffer resources: hardware bounds checking instead of branches ------------------------------------------

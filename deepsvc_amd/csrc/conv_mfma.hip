@@ -353,6 +353,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     p.pre_act = d->pre_act; p.act = d->act; p.slope = d->slope;
     p.res1 = d->res1; p.res1_ld = d->res1_ld; p.res1_dtype = d->res1_dtype; p.res1_scale = d->res1_scale;
     p.res2 = d->res2; p.res2_ld = d->res2_ld; p.res2_dtype = d->res2_dtype;
+    p.post_w = d->post_weight; p.post_bias = d->post_bias;
     p.out = d->out; p.out_ld = d->out_ld; p.out_dtype = d->out_dtype; p.shuffle = d->shuffle;
     // 4-channel vector access (16 B fp32 / 8 B bf16) is legal when base and pixel pitch keep that alignment
     auto vec4_ok = [](const void* ptr, int ld, int dtype) {
@@ -381,6 +382,11 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     if (p.s2d) {                            // only the general kernel's staging understands the space-to-depth view
         DSVC_REQUIRE(fast, "conv2d: s2d needs the vector staging path");
         opt.specialised = 0;
+    }
+    if (p.post_w) {                          // fused trailing 1x1 conv: only the two-group 3x3 kernel implements it
+        const int rc = dsvc_conv3x3_pp_try((hipStream_t)stream, p, d);
+        DSVC_REQUIRE(rc != 1, "conv2d: post_weight (fused 1x1) is not supported for this shape / type combination");
+        return rc;
     }
     if (opt.specialised && opt.direct) {    // small images (entropy-scan nets): barrier-free kernel, fragments straight from L2
         const int rc = dsvc_conv3x3_direct_try((hipStream_t)stream, p, d);

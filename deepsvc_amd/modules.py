@@ -228,8 +228,21 @@ class ResBottleneckBlock(nn.Module):
         self.conv3 = Conv2d(channel, channel, 1, 1, padding=0)
         self._act, self._slope = _act_code(slope)
 
+    def _fuse_tail_ok(self, x, o, out):
+        """conv2 -> act -> conv3 -> + x as ONE launch (the 1x1 rides on the 3x3 kernel's epilogue, include/dsvc.h:
+        post_weight) where the two-group 3x3 kernel applies: bf16 mode, 64 channels, bf16 16-byte-aligned tensors,
+        >= 1024 tiles of 8x32 pixels.  Saves a full read + write of the activation per block."""
+        if not (ops.FUSE_1X1[0] and ops.RT.compute == N.BF16 and self.conv2.in_channels == 64 and self.conv2.out_channels == 64):
+            return False
+        ok = lambda a: a.dtype == torch.bfloat16 and a.C == 64 and a.ld % 8 == 0 and a.ptr % 16 == 0
+        tiles = x.B * (-(-x.H // 8)) * (-(-x.W // 32))
+        return ok(x) and ok(o) and (out is None or ok(out)) and tiles >= 1024 and x.B * x.H * x.W < (1 << 24)
+
     def run(self, x, out=None):
         o = self.conv1.run(x, act=self._act, slope=self._slope)
+        if self._fuse_tail_ok(x, o, out):
+            post = self.conv3._packed([64], o.device)
+            return self.conv2.run(o, out, act=self._act, slope=self._slope, res1=x, post=post, out_dtype=torch.bfloat16)
         o = self.conv2.run(o, act=self._act, slope=self._slope)
         return self.conv3.run(o, out, res1=x)
 

@@ -57,6 +57,7 @@ def _stream():
 import threading as _threading
 
 _fork_pools = _threading.local()
+FUSE_1X1 = [_os.environ.get("DSVC_NO_FUSE_1X1", "") == ""]   # ResBottleneck conv2 -> act -> conv3 -> + x in one launch (bf16, 64 ch)
 S2D = [_os.environ.get("DSVC_NO_S2D", "") == ""]       # conv5x5/s2 through the space-to-depth view (bf16 mode)
 USE_FORKS = [_os.environ.get("DSVC_FORKS", "") != ""]   # opt-in: measured 17.15 vs 17.6 fps (event edges cost more than the overlap)
 
@@ -252,7 +253,7 @@ PROFILE = None
 
 
 def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.01, res1=None, gate=None, res2=None,
-           shuffle=1, out_dtype=None):
+           shuffle=1, out_dtype=None, post=None):
     """Run one fused conv.  inputs: list of Act (virtual torch.cat along channels)."""
     x0 = inputs[0]
     _require_gpu(x0.buf)
@@ -278,6 +279,10 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
         assert s2d or (a.B, a.H, a.W) == (B, H, W)
         d.seg[i].ptr, d.seg[i].C, d.seg[i].ld, d.seg[i].dtype = a.ptr, a.C * mult, a.ld, a.code
     d.s2d = 1 if s2d else 0
+    if post is not None:                    # fused trailing 1x1 conv (include/dsvc.h: post_weight): out = post(act(conv)) + res1
+        assert (post.kh, post.kw, post.Cout, post.segC) == (1, 1, pc.Cout, (pc.Cout,)) and post.compute == pc.compute
+        d.post_weight = post.weight.data_ptr()
+        d.post_bias = None if post.bias is None else post.bias.data_ptr()
     d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, pc.stride, pc.pad
     d.Cout, d.compute = pc.Cout, pc.compute
     d.weight = pc.weight.data_ptr()

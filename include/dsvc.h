@@ -96,6 +96,14 @@ typedef struct dsvc_conv_desc {
      * 5x5 stride-2 kernel is exactly a 3x3 stride-1 kernel over this view (weights remapped once on the host), which
      * avoids both the 25-tap weight re-staging per tile and the padding of 8-channel segments to 32-channel chunks. */
     int32_t s2d;
+    /* Optional pointwise conv fused behind the activation (ResBottleneckBlock's conv2 -> LeakyReLU -> conv3 -> + x,
+     * modules.py:173-189 == image_model.py:22-38):
+     *     out = post_weight * act(conv + bias) + post_bias + res1
+     * post_weight: packed weights (dsvc_conv_pack_weights) of a 1x1 conv Cout -> Cout, post_bias: device [Cout] fp32 or NULL.
+     * The intermediate act(conv + bias) is rounded to the compute type exactly as if it had been stored and re-read.
+     * Supported where the two-group 3x3 kernel applies (bf16, 64 -> 64 channels, >= 1024 tiles, bf16 NHWC in/out/res1,
+     * no res2 / gate / shuffle); dsvc_conv2d fails with DSVC_E_ARG otherwise -- callers fuse only then. */
+    const void* post_weight; const float* post_bias;
 } dsvc_conv_desc;
 
 /* bytes of the packed weight buffer for a conv with these input segments */

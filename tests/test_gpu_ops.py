@@ -305,6 +305,39 @@ def test_conv5x5s2_space_to_depth_view(segs, cout, B, H, W):
     report_close("s2d vs direct 5x5/s2", got, direct, 5e-3, tol)
 
 
+@pytest.mark.parametrize("B,H,W,slope", [(1, 256, 1024, 0.01), (1, 250, 1100, 0.01), (2, 130, 1000, 0.0)])
+def test_res_bottleneck_fused_tail(B, H, W, slope):
+    """ResBottleneckBlock (modules.py:173-189) with conv2 -> act -> conv3 -> + x fused into one launch of the two-group 3x3
+    kernel (include/dsvc.h: post_weight) against the three-launch execution and against torch on bf16-rounded operands."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import ResBottleneckBlock
+    torch.manual_seed(H + W)
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    try:
+        m = ResBottleneckBlock(64, slope=slope).to(DEV)
+        x = torch.randn(B, 64, H, W)
+        xa = _act(x, bf)
+        assert m._fuse_tail_ok(xa, xa, None)
+        fused = m.run(xa).nchw().float().cpu()
+        ops.FUSE_1X1[0] = False
+        try:
+            plain = m.run(xa).nchw().float().cpu()
+        finally:
+            ops.FUSE_1X1[0] = True
+    finally:
+        ops.set_precision("fp32")
+    r = lambda t: t.to(bf).float()
+    act = (lambda t: F.relu(t)) if slope < 1e-4 else (lambda t: F.leaky_relu(t, slope))
+    xb = r(x)
+    o1 = r(act(F.conv2d(xb, r(m.conv1.weight.detach().cpu()), m.conv1.bias.detach().cpu())))
+    o2 = r(act(F.conv2d(o1, r(m.conv2.weight.detach().cpu()), m.conv2.bias.detach().cpu(), padding=1)))
+    want = F.conv2d(o2, r(m.conv3.weight.detach().cpu()), m.conv3.bias.detach().cpu()) + xb
+    tol = 2e-2 * float(want.abs().max())
+    report_close("fused vs torch", fused, want, 2e-2, tol)
+    report_close("fused vs three launches", fused, plain, 1e-2, 0.5 * tol)
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
 def test_conv1x1_streaming_kernel(cin, cout):
     """Large bf16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,
