@@ -79,6 +79,62 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
     return rows
 
 
+def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None):
+    """Throughput mode: code the independent GOPs `gops` = [(frames, sm_feas), ...] on len(models) concurrent LANES of one
+    GPU.  A lane is one model instance (own weights, scan workspaces and HIP graphs), one stream and one host thread; GOP u
+    goes to lane u % L.  One GOP alone leaves the GPU idle ~20 % of a frame while the host range-decodes each scan level
+    (sequential by bitstream format); other lanes' kernels fill those gaps.  Results are identical to
+    coding the GOPs one after the other with code_gop (every kernel is deterministic); rows come back ordered by GOP.
+
+    Weight packing and HIP-graph capture need a quiescent device, so each lane is first warmed up alone on the first
+    P-frame of its first GOP (result discarded) until its graphs are in place."""
+    import threading
+    L = len(models)
+    assert L >= 1 and (i_models is None or len(i_models) == L)
+    streams = [torch.cuda.Stream(device) for _ in range(L)]
+    mine = [[u for u in range(len(gops)) if u % L == ln] for ln in range(L)]
+
+    def warm(ln):
+        if not mine[ln]:
+            return
+        frames, sms = gops[mine[ln][0]]
+        with torch.cuda.stream(streams[ln]):
+            ref, cur = pad(frames[0], 64), pad(frames[1], 64)
+            mv, res = models[ln].compress(ref, cur, sms[1], None)
+            models[ln].decompress(ref, mv, res, sms[1], None)
+            streams[ln].synchronize()
+
+    for _ in range(4):                       # a lane's graphs are final only once every lane has packed its weights
+        todo = [ln for ln in range(L) if mine[ln] and not models[ln].graphs_ready(
+            1, -(-gops[mine[ln][0]][0][0].shape[-2] // 64) * 64, -(-gops[mine[ln][0]][0][0].shape[-1] // 64) * 64, device)]
+        if not todo:
+            break
+        for ln in todo:
+            warm(ln)
+    out, errors = {}, []
+
+    def lane(ln):
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(streams[ln]):
+                for u in mine[ln]:
+                    frames, sms = gops[u]
+                    out[u] = code_gop(models[ln], frames, sms, unit=u, sync=streams[ln].synchronize, metrics=metrics,
+                                      i_model=None if i_models is None else i_models[ln])
+                streams[ln].synchronize()
+        except BaseException as e:          # surfaced in the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=lane, args=(ln,)) for ln in range(L)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return [row for u in range(len(gops)) for row in out[u]]
+
+
 def gather_rows(rows, device, world_size):
     """All ranks' metric rows -> one [n, len(METRIC_COLUMNS)] fp64 CPU tensor on every rank."""
     local = torch.tensor(rows, dtype=torch.float64, device=device).reshape(-1, len(METRIC_COLUMNS))

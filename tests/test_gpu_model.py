@@ -318,3 +318,27 @@ def test_4k_whole_frame_round_trip_bf16():
         assert tuple(mv["shape"]) == (34, 60) and torch.isfinite(r1).all()
     finally:
         ops.set_precision("fp32")
+
+
+def test_gop_lanes_match_sequential_coding():
+    """harness.code_gops_in_lanes (throughput mode: independent GOPs on concurrent lanes of one GPU, each with its own model
+    instance / stream / thread) returns exactly the rows of coding the GOPs one after the other."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("bf16")
+    try:
+        size, n_gops = 256, 3
+        gops = []
+        for u in range(n_gops):
+            frames = [f.to(DEV) for f in synth.make_frames(size, size, 3, seed=100 + u)]
+            sms = [None] + [synth.make_sm_fea(size, size, t, seed=100 + u).to(DEV) for t in (1, 2)]
+            gops.append((frames, sms))
+        models = []
+        for _ in range(2):
+            m = synth.make_model("W0"); m.update(force=True); models.append(m.to(DEV))
+        seq = [row for u, (fr, sm) in enumerate(gops) for row in harness.code_gop(models[0], fr, sm, unit=u, sync=torch.cuda.synchronize)]
+        par = harness.code_gops_in_lanes(models, gops, torch.device(DEV))
+        assert len(par) == len(seq) == n_gops * 2
+        for a, b in zip(seq, par):
+            assert a[:7] == b[:7], (a[:7], b[:7])            # unit, frame, bpp_mv, bpp_res, psnr x3: bit-identical results
+    finally:
+        ops.set_precision("fp32")
