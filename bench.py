@@ -75,7 +75,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if os.environ.get("DSVC_BENCH_REHEARSAL"):      # N ranks sharing the ONE GPU of a development box: gloo, all on cuda:0
+            dist.init_process_group(backend="gloo")        # (exercises the rank / barrier / gather plumbing, not RCCL)
+            local_rank = 0
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
