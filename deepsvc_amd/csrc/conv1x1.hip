@@ -10,12 +10,121 @@
 //   * the weights (<= 128x128, <= 40 KiB) are staged into LDS once per workgroup and read as B fragments per MFMA
 //     (keeping them in registers cost occupancy: 245 VGPRs at 96->96); output channels go in pairs of N-tiles;
 //   * the epilogue is the shared fused pass (bias, activation, gated residual, second residual, cast) through a
-//     wave-private LDS slab so that stores are 16-B vectors along the NHWC channel axis.
+//     wave-private LDS slab so that stores are 16-B vectors along the NHWC channel axis -- or, for the common case
+//     (bf16 out, activation in {none, ReLU, LeakyReLU}, at most one bf16 residual: conv1 / conv3 of every
+//     ResBottleneckBlock), a register epilogue: operand roles swapped (D[channel][pixel]), one v_permlane32_swap per
+//     register so that each lane holds 8 consecutive channels of its pixel, bias preloaded into the accumulators, the
+//     residual prefetched one unit ahead as 16-B vectors.  The slab path ran the residual case at 2.6 TB/s (118 us for
+//     96->96 @544x960 against 46 us without residual).
+#include <cstdlib>
 #include "conv_common.h"
 
 using namespace dsvc_conv;
 
 namespace {
+
+__device__ __forceinline__ unsigned pk_bf16_1x1(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// register-epilogue variant (see the header): act(x) = max(x, x * act_slope) (slope 1: none, 0: ReLU)
+template <int KS, int NT, bool HAS_R1>
+__global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p, int nunits, float act_slope) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NCH = (KS + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    char* lds_w = smem;                                              // weights [chunk][Np rows] at the 80-B pitch
+    float* lds_bias = (float*)(smem + (size_t)NCH * p.Np * ROWB);    // Np floats
+    {
+        const int nrows = NCH * p.Np, q = tid & 3;
+        for (int row = tid >> 2; row < nrows; row += 64)
+            *(uint4*)(lds_w + row * ROWB + q * 16) = *(const uint4*)((const char*)p.w + (size_t)row * 64 + q * 16);
+        for (int c = tid; c < p.Np; c += 256) lds_bias[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+    }
+    __syncthreads();
+    const rsrc_t rin = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
+    const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
+    const rsrc_t rr1 = make_rsrc(HAS_R1 ? p.res1 : p.out, HAS_R1 ? p.res1_bytes : p.out_bytes);
+    const unsigned pitch = (unsigned)p.seg[0].ld * 2, opitch = (unsigned)p.out_ld * 2, rpitch = (unsigned)p.res1_ld * 2;
+    const unsigned npix = (unsigned)p.Wo;
+    const int nwaves = gridDim.x * 4;
+    int unit = blockIdx.x * 4 + wave;
+    auto load_a = [&](int u, uint4 (&a)[KS]) {
+        const unsigned pix = (unsigned)u * 32 + r;
+        const unsigned m = (pix < npix && u < nunits) ? 0u : OOB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = buf_load16(rin, (pix * pitch + h * 16 + ks * 32) | m);
+    };
+    // lane (r, h) ends up with channels n*32 + 16*P + 8*h .. +7 of pixel unit*32 + r
+    auto load_r = [&](int u, uint4 (&rv)[NT * 2]) {
+        const unsigned pix = (unsigned)u * 32 + r;
+        const bool okp = pix < npix && u < nunits;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                const int co = n * 32 + 16 * P + 8 * h;
+                rv[n * 2 + P] = buf_load16(rr1, (pix * rpitch + (unsigned)co * 2) | ((okp && co < p.Cout) ? 0u : OOB));
+            }
+    };
+    const int b_lane = r * ROWB + h * 16;
+    uint4 a_cur[KS], a_nxt[KS], r_cur[NT * 2], r_nxt[NT * 2];
+    load_a(unit, a_cur);
+    if constexpr (HAS_R1) load_r(unit, r_cur);
+    for (; unit < nunits; unit += nwaves) {
+        load_a(unit + nwaves, a_nxt);                          // prefetch (masked past the end)
+        if constexpr (HAS_R1) load_r(unit + nwaves, r_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned pix = (unsigned)unit * 32 + r;
+        const bool okp = pix < npix;
+#define C1D_TILE(N0)                                                                                                 \
+    if constexpr (N0 < NT) {                                                                                         \
+        f32x16 acc;                                                                                                  \
+        _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {      /* accumulator row (reg i) = channel (i&3) + 8*(i>>2) + 4*h */ \
+            const float4 bq = *(const float4*)(lds_bias + N0 * 32 + 8 * qd + 4 * h);                                  \
+            acc[4 * qd] = bq.x; acc[4 * qd + 1] = bq.y; acc[4 * qd + 2] = bq.z; acc[4 * qd + 3] = bq.w;              \
+        }                                                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
+            const uint4 bw = *(const uint4*)(lds_w + ((ks >> 1) * p.Np + N0 * 32) * ROWB + b_lane + (ks & 1) * 32);   \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, a_cur[ks]), acc, 0, 0, 0); \
+        }                                                                                                            \
+        _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                              \
+            float v[8];                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                          \
+                const float xq = acc[8 * P + j], yq = acc[8 * P + 4 + j];   /* scalars first: hipcc 7.2 mis-casts vector elements */ \
+                const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false); \
+                const unsigned lo_ = sw.x, hi_ = sw.y;                                                               \
+                v[j] = __builtin_bit_cast(float, lo_); v[4 + j] = __builtin_bit_cast(float, hi_);                    \
+            }                                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], v[j] * act_slope, __builtin_inff()); \
+            if constexpr (HAS_R1) {                                                                                  \
+                const uint4 a = r_cur[N0 * 2 + P];                                                                   \
+                const unsigned ua[4] = {a.x, a.y, a.z, a.w};                                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+                    v[2 * j] += __builtin_bit_cast(float, ua[j] << 16);                                              \
+                    v[2 * j + 1] += __builtin_bit_cast(float, ua[j] & 0xFFFF0000u);                                  \
+                }                                                                                                    \
+            }                                                                                                        \
+            const int co = N0 * 32 + 16 * P + 8 * h;                                                                 \
+            v4u_t ov;                                                                                                \
+            ov.x = pk_bf16_1x1(v[0], v[1]); ov.y = pk_bf16_1x1(v[2], v[3]); ov.z = pk_bf16_1x1(v[4], v[5]); ov.w = pk_bf16_1x1(v[6], v[7]); \
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rout, (pix * opitch + (unsigned)co * 2) | ((okp && co < p.Cout) ? 0u : OOB), 0, 0); \
+        }                                                                                                            \
+    }
+        C1D_TILE(0) C1D_TILE(1) C1D_TILE(2) C1D_TILE(3)
+#undef C1D_TILE
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+        if constexpr (HAS_R1) {
+#pragma unroll
+            for (int i = 0; i < NT * 2; ++i) r_cur[i] = r_nxt[i];
+        }
+    }
+}
 
 template <int KS, int NT>
 __global__ void __launch_bounds__(256) conv1x1_kernel(const ConvParams p, int nunits) {
@@ -92,6 +201,27 @@ int launch_1x1(hipStream_t st, const ConvParams& p, int nunits) {
     return DSVC_OK;
 }
 
+template <int KS, int NT>
+int launch_1x1_direct(hipStream_t st, const ConvParams& p, int nunits, float act_slope) {
+    const size_t lds = (size_t)((KS + 1) / 2) * p.Np * ROWB + (size_t)p.Np * sizeof(float);
+    int grid = (nunits + 3) / 4;
+    if (grid > 256 * 4) grid = 256 * 4;
+    if (p.res1) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, true>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
+    else hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
+    DSVC_CHECK_LAUNCH("conv1x1_direct_kernel");
+    return DSVC_OK;
+}
+
+template <int KS>
+int launch_1x1_direct_nt(hipStream_t st, const ConvParams& p, int nunits, int NT, float act_slope) {
+    switch (NT) {
+        case 1: return launch_1x1_direct<KS, 1>(st, p, nunits, act_slope);
+        case 2: return launch_1x1_direct<KS, 2>(st, p, nunits, act_slope);
+        case 3: return launch_1x1_direct<KS, 3>(st, p, nunits, act_slope);
+        default: return launch_1x1_direct<KS, 4>(st, p, nunits, act_slope);
+    }
+}
+
 template <int KS>
 int launch_1x1_nt(hipStream_t st, const ConvParams& p, int nunits, int NT) {
     switch (NT) {
@@ -116,6 +246,21 @@ int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_des
     p.B = 1; p.Ho = 1; p.Wo = (int)npix;                        // flat pixel list: offsets are pixel-linear
     const int nunits = (int)((npix + 31) / 32);
     const int NT = (d->Cout + 31) / 32;
+    // register epilogue: bf16 out, activation none / ReLU / LeakyReLU, at most one plain bf16 residual, 16-byte rows
+    float act_slope = 1.f;
+    const bool act_ok = d->act == DSVC_ACT_NONE || (d->act == DSVC_ACT_RELU ? (act_slope = 0.f, true)
+                        : (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f ? (act_slope = d->slope, true) : false));
+    auto v16 = [](const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (ld % 8) == 0; };
+    static const bool direct_on = getenv("DSVC_1X1_SLAB") == nullptr;
+    if (direct_on && act_ok && d->out_dtype == DSVC_BF16 && v16(d->out, d->out_ld) && (d->Cout % 8) == 0 && !d->res2 && !d->res1_scale &&
+        (!d->res1 || (d->res1_dtype == DSVC_BF16 && v16(d->res1, d->res1_ld))) && npix < (1 << 24)) {
+        switch (sg.C / 16) {
+            case 2: return launch_1x1_direct_nt<2>(st, p, nunits, NT, act_slope);
+            case 4: return launch_1x1_direct_nt<4>(st, p, nunits, NT, act_slope);
+            case 6: return launch_1x1_direct_nt<6>(st, p, nunits, NT, act_slope);
+            default: return launch_1x1_direct_nt<8>(st, p, nunits, NT, act_slope);
+        }
+    }
     switch (sg.C / 16) {
         case 2: return launch_1x1_nt<2>(st, p, nunits, NT);
         case 4: return launch_1x1_nt<4>(st, p, nunits, NT);

@@ -338,6 +338,36 @@ def test_res_bottleneck_fused_tail(B, H, W, slope):
     report_close("fused vs three launches", fused, plain, 1e-2, 0.5 * tol)
 
 
+@pytest.mark.parametrize("cin,cout,act,res", [(64, 64, 2, True), (96, 96, 0, True), (96, 96, 2, False), (128, 128, 1, True),
+                                              (32, 64, 0, False), (64, 40, 2, True)])
+def test_conv1x1_register_epilogue(cin, cout, act, res):
+    """bf16-out 1x1 convs with activation in {none, ReLU, LeakyReLU} and at most one bf16 residual (conv1 / conv3 of the
+    ResBottleneck blocks) take the register epilogue of csrc/conv1x1.hip: ragged pixel count, partial last N-tile."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(cin * 3 + cout)
+    H, W = 250, 333              # 83250 pixels: not a multiple of 32
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(cin, cout, 1, 1, 0).to(DEV)
+        x, r1 = torch.randn(1, cin, H, W), torch.randn(1, cout, H, W)
+        kw = dict(act=act, slope=0.05)
+        if res:
+            kw["res1"] = _act(r1, bf)
+        got = m.run(_act(x, bf), out_dtype=bf, **kw).nchw().float().cpu()
+        slab = m.run(_act(x, bf), out_dtype=torch.float32, **kw).nchw().cpu()          # fp32 out: LDS-slab epilogue
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    want = _torch_act(F.conv2d(x.to(bf).float(), w, b), act, 0.05)
+    if res:
+        want = want + r1.to(bf).float()
+    tol = 2e-2 * float(want.abs().max())
+    report_close("1x1 register epilogue vs torch", got, want, 2e-2, tol)
+    report_close("1x1 register vs slab epilogue", got, slab, 1e-2, 0.5 * tol)
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
 def test_conv1x1_streaming_kernel(cin, cout):
     """Large bf16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,

@@ -30,6 +30,11 @@ SHAPES = [  # (name, segs, cout, k, stride, H, W, kwargs)
     ("3x3 64+64->64 @1/1", (64, 64), 64, 3, 1, 1088, 1920, {}),
     ("3x3 128->128 @1/4 +res", (128,), 128, 3, 1, 272, 480, {"res": True}),
     ("7x7 32->64 @1/1", (32,), 64, 7, 1, 1088, 1920, {}),
+    ("1x1 96->96 @1/2", (96,), 96, 1, 1, 544, 960, {}),
+    ("1x1 96->96 @1/2 +res", (96,), 96, 1, 1, 544, 960, {"res": True}),
+    ("1x1 128->128 @1/2", (128,), 128, 1, 1, 544, 960, {}),
+    ("1x1 64->64 @1/2", (64,), 64, 1, 1, 544, 960, {}),
+    ("1x1 32->32 @1/1", (32,), 32, 1, 1, 1088, 1920, {}),
 ]
 
 
