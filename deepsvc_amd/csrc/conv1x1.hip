@@ -30,7 +30,9 @@ __device__ __forceinline__ unsigned pk_bf16_1x1(float a, float b) {
 }
 
 // register-epilogue variant (see the header): act(x) = max(x, x * act_slope) (slope 1: none, 0: ReLU)
-template <int KS, int NT, bool HAS_R1>
+// Up to two input segments of whole 32-channel chunks (the virtual torch.cat of the up-path ConvBlockResidual shortcuts);
+// HAS_GATE: out = act(conv) + gate[c] * res1 (the SE gate of modules.py:226-247, batch 1).
+template <int KS, int NT, bool HAS_R1, bool HAS_GATE>
 __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p, int nunits, float act_slope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NCH = (KS + 1) / 2;
@@ -38,15 +40,22 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     char* lds_w = smem;                                              // weights [chunk][Np rows] at the 80-B pitch
-    float* lds_bias = (float*)(smem + (size_t)NCH * p.Np * ROWB);    // Np floats
+    float* lds_bias = (float*)(smem + (size_t)NCH * p.Np * ROWB);    // Np floats (+ Np floats of the gate)
     {
         const int nrows = NCH * p.Np, q = tid & 3;
         for (int row = tid >> 2; row < nrows; row += 64)
             *(uint4*)(lds_w + row * ROWB + q * 16) = *(const uint4*)((const char*)p.w + (size_t)row * 64 + q * 16);
-        for (int c = tid; c < p.Np; c += 256) lds_bias[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        for (int c = tid; c < p.Np; c += 256) {
+            lds_bias[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+            if constexpr (HAS_GATE) lds_bias[p.Np + c] = c < p.Cout ? p.res1_scale[c] : 0.f;
+        }
     }
     __syncthreads();
     const rsrc_t rin = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
+    const bool two = p.nseg > 1;
+    const rsrc_t rin1 = make_rsrc(p.seg[two ? 1 : 0].ptr, p.seg[two ? 1 : 0].bytes);
+    const int ks0 = two ? p.seg[0].C / 16 : KS;                      // k-steps served by segment 0
+    const unsigned pitch1 = (unsigned)p.seg[two ? 1 : 0].ld * 2;
     const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
     const rsrc_t rr1 = make_rsrc(HAS_R1 ? p.res1 : p.out, HAS_R1 ? p.res1_bytes : p.out_bytes);
     const unsigned pitch = (unsigned)p.seg[0].ld * 2, opitch = (unsigned)p.out_ld * 2, rpitch = (unsigned)p.res1_ld * 2;
@@ -57,7 +66,9 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
         const unsigned pix = (unsigned)u * 32 + r;
         const unsigned m = (pix < npix && u < nunits) ? 0u : OOB;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = buf_load16(rin, (pix * pitch + h * 16 + ks * 32) | m);
+        for (int ks = 0; ks < KS; ++ks)
+            a[ks] = ks < ks0 ? buf_load16(rin, (pix * pitch + h * 16 + ks * 32) | m)
+                             : buf_load16(rin1, (pix * pitch1 + h * 16 + (ks - ks0) * 32) | m);
     };
     // lane (r, h) ends up with channels n*32 + 16*P + 8*h .. +7 of pixel unit*32 + r
     auto load_r = [&](int u, uint4 (&rv)[NT * 2]) {
@@ -104,9 +115,19 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
             if constexpr (HAS_R1) {                                                                                  \
                 const uint4 a = r_cur[N0 * 2 + P];                                                                   \
                 const unsigned ua[4] = {a.x, a.y, a.z, a.w};                                                         \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
-                    v[2 * j] += __builtin_bit_cast(float, ua[j] << 16);                                              \
-                    v[2 * j + 1] += __builtin_bit_cast(float, ua[j] & 0xFFFF0000u);                                  \
+                if constexpr (HAS_GATE) {                                                                            \
+                    const float4 g0 = *(const float4*)(lds_bias + p.Np + N0 * 32 + 16 * P + 8 * h);                  \
+                    const float4 g1 = *(const float4*)(lds_bias + p.Np + N0 * 32 + 16 * P + 8 * h + 4);              \
+                    const float gt[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};                            \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+                        v[2 * j] += gt[2 * j] * __builtin_bit_cast(float, ua[j] << 16);                              \
+                        v[2 * j + 1] += gt[2 * j + 1] * __builtin_bit_cast(float, ua[j] & 0xFFFF0000u);              \
+                    }                                                                                                \
+                } else {                                                                                             \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+                        v[2 * j] += __builtin_bit_cast(float, ua[j] << 16);                                          \
+                        v[2 * j + 1] += __builtin_bit_cast(float, ua[j] & 0xFFFF0000u);                              \
+                    }                                                                                                \
                 }                                                                                                    \
             }                                                                                                        \
             const int co = N0 * 32 + 16 * P + 8 * h;                                                                 \
@@ -203,11 +224,12 @@ int launch_1x1(hipStream_t st, const ConvParams& p, int nunits) {
 
 template <int KS, int NT>
 int launch_1x1_direct(hipStream_t st, const ConvParams& p, int nunits, float act_slope) {
-    const size_t lds = (size_t)((KS + 1) / 2) * p.Np * ROWB + (size_t)p.Np * sizeof(float);
+    const size_t lds = (size_t)((KS + 1) / 2) * p.Np * ROWB + (size_t)2 * p.Np * sizeof(float);
     int grid = (nunits + 3) / 4;
     if (grid > 256 * 4) grid = 256 * 4;
-    if (p.res1) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, true>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
-    else hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
+    if (p.res1 && p.res1_scale) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, true, true>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
+    else if (p.res1) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, true, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
+    else hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, false, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
     DSVC_CHECK_LAUNCH("conv1x1_direct_kernel");
     return DSVC_OK;
 }
@@ -237,9 +259,16 @@ int launch_1x1_nt(hipStream_t st, const ConvParams& p, int nunits, int NT) {
 // returns 1 when the shape is not covered (caller falls back to the generic kernel), else DSVC_OK / error
 int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
     if (d->compute != DSVC_BF16 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->shuffle != 1) return 1;
-    if (d->nseg != 1 || d->pre_act != DSVC_ACT_NONE || !p_in.epi_vec || (d->res1_scale && d->B > 1)) return 1;
-    const ConvSeg& sg = p_in.seg[0];
-    if (sg.dtype != DSVC_BF16 || !sg.vec_ok || (sg.C % 32) != 0 || sg.C > 128 || d->Cout > 128) return 1;
+    if (d->nseg > 2 || d->pre_act != DSVC_ACT_NONE || !p_in.epi_vec || (d->res1_scale && d->B > 1)) return 1;
+    int ctot = 0;
+    for (int s = 0; s < d->nseg; ++s) {                        // whole 32-channel chunks of aligned bf16 rows
+        const ConvSeg& g = p_in.seg[s];
+        if (g.dtype != DSVC_BF16 || !g.vec_ok || (g.C % 32) != 0) return 1;
+        ctot += g.C;
+    }
+    if (ctot > 128 || d->Cout > 128) return 1;
+    ConvSeg sg = p_in.seg[0];
+    sg.C = ctot;                                               // total input channels select the k-step count
     const int64_t npix = (int64_t)d->B * d->H * d->W;
     if (npix < 64 * 1024) return 1;                            // small images stay on the generic kernel
     ConvParams p = p_in;
@@ -252,8 +281,8 @@ int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_des
                         : (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f ? (act_slope = d->slope, true) : false));
     auto v16 = [](const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (ld % 8) == 0; };
     static const bool direct_on = getenv("DSVC_1X1_SLAB") == nullptr;
-    if (direct_on && act_ok && d->out_dtype == DSVC_BF16 && v16(d->out, d->out_ld) && (d->Cout % 8) == 0 && !d->res2 && !d->res1_scale &&
-        (!d->res1 || (d->res1_dtype == DSVC_BF16 && v16(d->res1, d->res1_ld))) && npix < (1 << 24)) {
+    if (direct_on && act_ok && d->out_dtype == DSVC_BF16 && v16(d->out, d->out_ld) && (d->Cout % 8) == 0 && !d->res2 &&
+        (!d->res1_scale || d->res1) && (!d->res1 || (d->res1_dtype == DSVC_BF16 && v16(d->res1, d->res1_ld))) && npix < (1 << 24)) {
         switch (sg.C / 16) {
             case 2: return launch_1x1_direct_nt<2>(st, p, nunits, NT, act_slope);
             case 4: return launch_1x1_direct_nt<4>(st, p, nunits, NT, act_slope);
@@ -261,6 +290,7 @@ int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_des
             default: return launch_1x1_direct_nt<8>(st, p, nunits, NT, act_slope);
         }
     }
+    if (d->nseg != 1) return 1;                                // the LDS-slab variant reads one segment
     switch (sg.C / 16) {
         case 2: return launch_1x1_nt<2>(st, p, nunits, NT);
         case 4: return launch_1x1_nt<4>(st, p, nunits, NT);

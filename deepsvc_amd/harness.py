@@ -99,9 +99,14 @@ def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None):
             return
         frames, sms = gops[mine[ln][0]]
         with torch.cuda.stream(streams[ln]):
-            ref, cur = pad(frames[0], 64), pad(frames[1], 64)
-            mv, res = models[ln].compress(ref, cur, sms[1], None)
-            models[ln].decompress(ref, mv, res, sms[1], None)
+            ref, feat = pad(frames[0], 64), None
+            if i_models is not None:
+                enc = i_models[ln].compress(ref)
+                ref = i_models[ln].decompress(enc["strings"], enc["shape"])["x_hat"]
+            for t in range(1, min(len(frames), 3)):       # first AND steady-state P-frame: some layers are first used with `feature`
+                cur = pad(frames[t], 64)
+                mv, res = models[ln].compress(ref, cur, sms[t], feat)
+                feat, ref, _, _ = models[ln].decompress(ref, mv, res, sms[t], feat)
             streams[ln].synchronize()
 
     for _ in range(4):                       # a lane's graphs are final only once every lane has packed its weights

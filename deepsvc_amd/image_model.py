@@ -270,22 +270,34 @@ class ChannelSplitICIP2020ResB(nn.Module):
     # ------------------------------------------------------------------------------------------
     # scan plans: static workspace + HIP graphs of the launch-bound scan segments
     # ------------------------------------------------------------------------------------------
+    def _epoch_ref(self):
+        """Packing epoch of THIS codec: bumped by its own conv layers when their weights are (re)packed (modules.
+        _bump_owner_epoch).  The scan graphs hold pointers to exactly those buffers, so a pack elsewhere -- another model
+        instance running on a concurrent GOP lane, a lazily packed layer of the video model -- leaves them valid."""
+        ref = self.__dict__.get("_pack_epoch")
+        if ref is None:
+            ref = self.__dict__["_pack_epoch"] = [0]
+            for m in self.modules():
+                if isinstance(m, (Conv2d, Deconv5x5s2)):
+                    m.__dict__["_epoch_ref"] = ref
+        return ref
+
     def _plan(self, B, h, w, device):
         key = (B, h, w, str(device), ops.RT.mode)
         plans = self.__dict__.setdefault("_plans", {})
         plan = plans.get(key)
-        if plan is None or plan.epoch != ops.PACK_EPOCH[0]:
+        if plan is None or plan.epoch != self._epoch_ref()[0]:
             if plan is None:
                 plan = plans[key] = _ScanPlan(self, B, h, w, device)
             plan.graphs.clear()                  # weights were repacked since capture: the graphs hold stale pointers
-            plan.epoch = ops.PACK_EPOCH[0]
+            plan.epoch = self._epoch_ref()[0]
         return plan
 
     def _step(self, plan, key, fn):
         """Run one scan segment: replay its HIP graph when one has been captured for the current weights, else eagerly.
         A segment is a fixed sequence of ~20-90 tiny launches on static buffers with no host interaction -- exactly what
         a graph is for: the CPU cost per segment drops from ~30 us per launch to one graph launch."""
-        g = plan.graphs.get(key) if ops.USE_GRAPHS[0] and plan.epoch == ops.PACK_EPOCH[0] else None
+        g = plan.graphs.get(key) if ops.USE_GRAPHS[0] and plan.epoch == self._epoch_ref()[0] else None
         if g is not None:
             g.replay()
         else:
@@ -294,7 +306,7 @@ class ChannelSplitICIP2020ResB(nn.Module):
     def scan_graphs_ready(self, B, h, w, device):
         key = (B, h, w, str(device), ops.RT.mode)
         plan = self.__dict__.get("_plans", {}).get(key)
-        return plan is not None and plan.epoch == ops.PACK_EPOCH[0] and all(k in plan.graphs for k in self._segments(plan))
+        return plan is not None and plan.epoch == self._epoch_ref()[0] and all(k in plan.graphs for k in self._segments(plan))
 
     def capture_scan_graphs(self, B, h, w, device):
         """Capture the scan segments of this codec at latent shape (h, w).  Must be called from a quiescent point (no
@@ -312,11 +324,11 @@ class ChannelSplitICIP2020ResB(nn.Module):
         for t in (ws.z_sym, ws.sym_dev, ws.idx_dev, ws.staging):
             t.zero_()
         ws.y.buf.zero_()
-        epoch = ops.PACK_EPOCH[0]
+        epoch = self._epoch_ref()[0]
         for fn in steps.values():                 # eager warm-up on dummy data: packs weights, sets kernel attributes
             fn()
         torch.cuda.synchronize(device)
-        if ops.PACK_EPOCH[0] != epoch:            # something was packed just now: pointers may move again, retry later
+        if self._epoch_ref()[0] != epoch:            # something was packed just now: pointers may move again, retry later
             self._plan(B, h, w, device)
             return False
         for key, fn in steps.items():
@@ -473,6 +485,8 @@ class ChannelSplitICIP2020ResB(nn.Module):
         if scale_table is None:
             scale_table = get_scale_table()
         updated |= self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        if updated:                          # the device-side tables are rebuilt lazily: captured scan graphs hold the old ones
+            self._epoch_ref()[0] += 1
         return updated
 
     def aux_loss(self):

@@ -30,6 +30,14 @@ def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
 # ------------------------------------------------------------------------------------------------
 # parameter holders
 # ------------------------------------------------------------------------------------------------
+def _bump_owner_epoch(module):
+    """A codec whose HIP graphs hold this layer's packed-weight pointers registers a counter here (image_model._epoch_ref):
+    repacking the layer invalidates THAT codec's graphs only -- not those of other model instances (GOP lanes)."""
+    ref = module.__dict__.get("_epoch_ref")
+    if ref is not None:
+        ref[0] += 1
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d parameters (same keys) executed by the fused MFMA conv kernel."""
 
@@ -41,6 +49,7 @@ class Conv2d(nn.Conv2d):
             cache.clear()
             cache[key] = ops.PackedConv(self.weight, self.bias, seg_channels, self.stride[0], self.padding[0],
                                         ops.RT.compute, device, phys_channels, s2d=s2d)
+            _bump_owner_epoch(self)
         return cache[key]
 
     def _s2d_ok(self, phys_inputs):
@@ -115,6 +124,7 @@ class Deconv5x5s2(nn.ConvTranspose2d):
             cache.clear()
             w3, b4 = ops.deconv_as_conv_weights(self.weight, self.bias)
             cache[key] = ops.PackedConv(w3, b4, [self.in_channels], 1, 1, ops.RT.compute, device)
+            _bump_owner_epoch(self)
         return cache[key]
 
     def run(self, x, out=None, **epilogue):

@@ -65,13 +65,14 @@ class DeepSVC(nn.Module):
         once the weight-packing epoch has been stable for a whole call -- i.e. after the first frame."""
         if not ops.USE_GRAPHS[0]:
             return
-        epoch = ops.PACK_EPOCH[0]
+        epochs = lambda: (self.mv_codec._epoch_ref()[0], self.res_codec._epoch_ref()[0])
+        epoch = epochs()
         if self.__dict__.get("_seen_epoch") != epoch:
             self.__dict__["_seen_epoch"] = epoch
             return
         for codec in (self.mv_codec, self.res_codec):
             codec.capture_scan_graphs(ref.B, ref.H // 16, ref.W // 16, ref.device)
-        self.__dict__["_seen_epoch"] = ops.PACK_EPOCH[0]
+        self.__dict__["_seen_epoch"] = epochs()
 
     @staticmethod
     def _bpp(liks, pixels):

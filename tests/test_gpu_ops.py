@@ -338,6 +338,29 @@ def test_res_bottleneck_fused_tail(B, H, W, slope):
     report_close("fused vs three launches", fused, plain, 1e-2, 0.5 * tol)
 
 
+@pytest.mark.parametrize("segs,cout", [((32, 32), 64), ((64, 64), 64), ((64,), 32), ((64, 32), 128)])
+def test_conv1x1_gated_two_segment(segs, cout):
+    """ConvBlockResidual tails (modules.py:233-247): up_dim(cat[a, b]) + gate[c] * branch as one 1x1 launch with the register
+    epilogue (two input segments, SE gate on the residual)."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout)
+    H, W = 250, 333
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(sum(segs), cout, 1, 1, 0).to(DEV)
+        xs = [torch.randn(1, c, H, W) for c in segs]
+        r1, gate = torch.randn(1, cout, H, W), torch.rand(1, cout)
+        ins = [_act(x, bf) for x in xs]
+        got = m.run(ins if len(ins) > 1 else ins[0], res1=_act(r1, bf), gate=gate.to(DEV), out_dtype=bf).nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    want = F.conv2d(torch.cat([x.to(bf).float() for x in xs], 1), w, b) + gate[:, :, None, None] * r1.to(bf).float()
+    report_close("gated 1x1", got, want, 2e-2, 2e-2 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,act,res", [(64, 64, 2, True), (96, 96, 0, True), (96, 96, 2, False), (128, 128, 1, True),
                                               (32, 64, 0, False), (64, 40, 2, True)])
 def test_conv1x1_register_epilogue(cin, cout, act, res):

@@ -35,6 +35,9 @@ SHAPES = [  # (name, segs, cout, k, stride, H, W, kwargs)
     ("1x1 128->128 @1/2", (128,), 128, 1, 1, 544, 960, {}),
     ("1x1 64->64 @1/2", (64,), 64, 1, 1, 544, 960, {}),
     ("1x1 32->32 @1/1", (32,), 32, 1, 1, 1088, 1920, {}),
+    ("1x1 32+32->64 @1/1 gate+res", (32, 32), 64, 1, 1, 1088, 1920, {"res": True, "gate": True}),
+    ("1x1 64->32 @1/1 gate+res", (64,), 32, 1, 1, 1088, 1920, {"res": True, "gate": True}),
+    ("1x1 64+64->64 @1/2 gate+res", (64, 64), 64, 1, 1, 544, 960, {"res": True, "gate": True}),
 ]
 
 
@@ -57,6 +60,8 @@ def main():
         out = ops.new_act(1, Ho, Wo, cout, st, dev)
         res = ops.Act(torch.randn((1, Ho, Wo, cout), device=dev).to(st)) if kw.get("res") else None
         ep = dict(res1=res, pre_act=N.ACT_LRELU if kw.get("pre") else N.ACT_NONE, act=N.ACT_LRELU if kw.get("pre") else N.ACT_NONE)
+        if kw.get("gate"):
+            ep["gate"] = torch.rand((1, cout), device=dev)
         for _ in range(3):
             m.run(ins, out, **ep)
         torch.cuda.synchronize()
