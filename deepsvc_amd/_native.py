@@ -35,6 +35,7 @@ class ConvDesc(Structure):
         ("out", c_void_p), ("out_ld", c_int32), ("out_dtype", c_int32),
         ("s2d", c_int32),
         ("post_weight", c_void_p), ("post_bias", c_void_p),
+        ("batch_inner", c_int32), ("weight_bstride", c_int64), ("bias_bstride", c_int64), ("in_bstride", (c_int64 * 2) * 3),
     ]
 
 

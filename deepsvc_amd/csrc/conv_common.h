@@ -11,6 +11,7 @@ struct ConvSeg {
     const void* ptr;
     int C, ld, dtype, vec_ok, chunk0;
     unsigned bytes;      // extent from ptr to the end of the last pixel's slice (buffer-resource num_records)
+    unsigned bs_lo, bs_hi;   // byte offset of batch item b = (b % b_inner) * bs_lo + (b / b_inner) * bs_hi (dense: b * image bytes)
 };
 
 struct ConvParams {
@@ -31,6 +32,8 @@ struct ConvParams {
     int epi_vec;                                   // 1: epilogue may use 4-channel vector buffer ops everywhere
     int s2d;                                       // 1: inputs are a space-to-depth view of a (2H x 2W) image (dsvc.h)
     const void* post_w; const float* post_bias;    // fused trailing 1x1 conv (dsvc.h: post_weight), conv3x3_pp only
+    int b_inner;                                   // see ConvSeg::bs_lo (dense batch: INT_MAX)
+    long long w_bs; int bias_bs;                   // per-batch-item weights (dsvc.h: weight_bstride): bytes / floats per item, 0 = shared
 };
 
 // ---- raw buffer resources: hardware bounds checking instead of branches ------------------------------------------
@@ -113,7 +116,7 @@ __device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* 
     float bias[4] = {0.f, 0.f, 0.f, 0.f}, gate[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (p.bias && j < nv) bias[j] = p.bias[co + j];
+        if (p.bias && j < nv) bias[j] = p.bias[b * p.bias_bs + co + j];
         if (p.res1_scale && j < nv) gate[j] = p.res1_scale[(int64_t)b * p.Cout + co + j];
     }
     for (int pl = lane / GPP; pl < npl; pl += 64 / GPP) {
@@ -176,7 +179,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
     if (lane_ok) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (p.bias) bias[j] = p.bias[co + j];
+            if (p.bias) bias[j] = p.bias[b * p.bias_bs + co + j];
             if (p.res1_scale) gate[j] = p.res1_scale[(int64_t)b * p.Cout + co + j];
         }
     }

@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     const int ty = bid % p.tiles_y;
     const int b = bid / p.tiles_y;
     const int ng = blockIdx.y;
+    const unsigned b_lo = (unsigned)(b % p.b_inner), b_hi = (unsigned)(b / p.b_inner);   // dense batch: (b, 0)
 
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int PH = (TH - 1) * p.stride + p.kh, PW = (TW - 1) * p.stride + p.kw;
@@ -92,15 +93,60 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         lds_barrier();  // all waves done with the previous chunk's LDS contents (LDS-only: global traffic stays in flight)
         // ---- stage the input halo patch of this channel chunk ----
         // Loads of a batch are all issued before the first LDS store so their L2/HBM latencies overlap.
-        if constexpr (FAST) {  // storage type == compute type, 16-B aligned, whole chunks
+        bool staged = false;
+        if constexpr (FAST && sizeof(CT) == 2) {
+            // fp32 storage feeding the bf16 MFMA (the entropy scan's fp32 latents): two 16-B loads per quarter, batched like
+            // the same-type path, rounded to bf16 (RNE, as pack_vec does) on the way into LDS
+            if (sg.dtype == DSVC_F32) {
+                staged = true;
+                constexpr int PC = 4;
+                const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);
+                const unsigned pitch = (unsigned)sg.ld * 4u;
+                const unsigned img = b_lo * sg.bs_lo + b_hi * sg.bs_hi + (unsigned)(c0 + q * EPV) * 4u;
+                const unsigned m0 = c0 + q * EPV < sg.C ? 0u : OOB, m1 = c0 + q * EPV + 4 < sg.C ? 0u : OOB;   // C % 4 == 0
+                const float sl = p.pre_act == DSVC_ACT_RELU ? 0.f : (p.pre_act == DSVC_ACT_NONE ? 1.f : p.slope);
+                int py = py0, px = px0;
+                for (int base = pix0; base < npatch; base += 64 * PC) {
+                    uint4 lo[PC], hi[PC];
+                    int lr[PC];
+#pragma unroll
+                    for (int j = 0; j < PC; ++j) {
+                        const int iy = iy0 + py, ix = ix0 + px;
+                        lr[j] = lds_row(py, px);
+                        const bool inb = base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                        const unsigned off = (img + ((unsigned)iy * p.W + (unsigned)ix) * pitch) | (inb ? 0u : OOB);
+                        lo[j] = buf_load16(rs, off | m0);
+                        hi[j] = buf_load16(rs, (off + 16u) | m1 | (inb ? 0u : OOB));
+                        px += dpx; py += dpy;
+                        if (px >= PW) { px -= PW; ++py; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < PC; ++j) {
+                        float f[8] = {__builtin_bit_cast(float, lo[j].x), __builtin_bit_cast(float, lo[j].y),
+                                      __builtin_bit_cast(float, lo[j].z), __builtin_bit_cast(float, lo[j].w),
+                                      __builtin_bit_cast(float, hi[j].x), __builtin_bit_cast(float, hi[j].y),
+                                      __builtin_bit_cast(float, hi[j].z), __builtin_bit_cast(float, hi[j].w)};
+                        if (p.pre_act != DSVC_ACT_NONE) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], f[k] * sl);
+                        }
+                        const uint4 v = pack_vec<CT, 8>(f);
+                        if (base + 64 * j < npatch) *(uint4*)(lds_a + lr[j] * ROWB + q * 16) = v;
+                    }
+                }
+            }
+        }
+        if (staged) {
+        } else if constexpr (FAST) {  // storage type == compute type, 16-B aligned, whole chunks
             constexpr int PB = 6;
             const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);      // out-of-image pixels read as zeros (bounds-checked loads)
             const unsigned pitch = (unsigned)sg.ld * sizeof(CT);
             // plain: quarter q = channels c0 + q*EPV of the pixel.  space-to-depth view: quarter q = image pixel
             // (2Y + q/2, 2X + q%2), channels (chunk index in the segment) * EPV .. of a (2H x 2W) image
-            const unsigned img = p.s2d ? (unsigned)b * 4u * p.H * p.W * pitch + (unsigned)(ch - sg.chunk0) * 16u +
+            const unsigned img0 = b_lo * sg.bs_lo + b_hi * sg.bs_hi;
+            const unsigned img = p.s2d ? img0 + (unsigned)(ch - sg.chunk0) * 16u +
                                              ((unsigned)(q >> 1) * 2u * p.W + (unsigned)(q & 1)) * pitch
-                                       : (unsigned)b * p.H * p.W * pitch + c0 * (unsigned)sizeof(CT) + q * 16;
+                                       : img0 + c0 * (unsigned)sizeof(CT) + q * 16;
             const unsigned pixstep = p.s2d ? 2u : 1u, rowstep = p.s2d ? 4u * p.W : (unsigned)p.W;
             const bool qvalid = c0 + q * EPV < sg.C;           // a short last chunk: the missing 16-B quarters read as zeros
             int py = py0, px = px0;
@@ -166,7 +212,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             // ---- stage the weights of taps [tg0, tg0+tcur) for this chunk and N group (batched loads) ----
             {
                 constexpr int WB = 9;
-                const char* wbase = (const char*)p.w + (((size_t)ch * ntaps + tg0) * p.Np + (size_t)ng * NTN) * 64 + q * 16;
+                const char* wbase = (const char*)p.w + (size_t)b * p.w_bs + (((size_t)ch * ntaps + tg0) * p.Np + (size_t)ng * NTN) * 64 + q * 16;
                 const bool wfull = (ng + 1) * NTN <= p.Np;
                 const int nrows = tcur * NTN;
                 for (int base = tid >> 2; base < nrows; base += 64 * WB) {
@@ -323,6 +369,10 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
 
     ConvParams p{};
     const int kce = chunk_elems(d->compute);
+    const bool per_item = d->batch_inner > 0;    // batch items with their own weights and input offsets (dsvc.h: batch_inner)
+    if (per_item)
+        DSVC_REQUIRE(!d->s2d && !d->post_weight && !d->res1_scale && d->weight_bstride >= 0 && d->weight_bstride % 16 == 0 && d->bias_bstride >= 0,
+                     "conv2d: batch_inner excludes s2d / post_weight / res1_scale and needs 16-byte weight strides");
     int chunk0 = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const dsvc_seg& in = d->in[s];
@@ -337,9 +387,21 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
                                    : (((int64_t)d->B * d->H * d->W - 1) * in.ld + in.C) * es;
         DSVC_REQUIRE(ext < 0x7FFFFFF0ll, "conv2d: input segment %d spans %lld bytes (limit 2 GiB)", s, (long long)ext);
         p.seg[s] = ConvSeg{in.ptr, in.C, in.ld, in.dtype,
-                           (int)((((uintptr_t)in.ptr & 15) == 0) && (((int64_t)in.ld * es) % 16 == 0)), chunk0, (unsigned)ext};
+                           (int)((((uintptr_t)in.ptr & 15) == 0) && (((int64_t)in.ld * es) % 16 == 0)), chunk0, (unsigned)ext,
+                           (unsigned)((int64_t)(d->s2d ? 4 : 1) * d->H * d->W * in.ld * es), 0u};
+        if (per_item) {                      // explicit batch-item offsets instead of the dense [B,H,W,ld] layout
+            const int64_t lo = d->in_bstride[s][0], hi = d->in_bstride[s][1];
+            DSVC_REQUIRE(lo >= 0 && hi >= 0 && lo % 16 == 0 && hi % 16 == 0, "conv2d: in_bstride of segment %d must be non-negative multiples of 16", s);
+            const int64_t img = (((int64_t)d->H * d->W - 1) * in.ld + in.C) * es;
+            const int nlo = d->B < d->batch_inner ? d->B : d->batch_inner, nhi = (d->B + d->batch_inner - 1) / d->batch_inner;
+            const int64_t e2 = (nlo - 1) * lo + (nhi - 1) * hi + img;
+            DSVC_REQUIRE(e2 < 0x7FFFFFF0ll, "conv2d: input segment %d spans %lld bytes (limit 2 GiB)", s, (long long)e2);
+            p.seg[s].bytes = (unsigned)e2; p.seg[s].bs_lo = (unsigned)lo; p.seg[s].bs_hi = (unsigned)hi;
+        }
         chunk0 += (in.C + kce - 1) / kce;
     }
+    p.b_inner = per_item ? d->batch_inner : 0x7FFFFFFF;
+    p.w_bs = per_item ? d->weight_bstride : 0; p.bias_bs = per_item ? (int)d->bias_bstride : 0;
     p.nseg = d->nseg; p.nchunks = chunk0;
     p.B = d->B; p.H = d->H; p.W = d->W;
     p.s2d = d->s2d ? 1 : 0;
@@ -375,12 +437,14 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     }
     bool fast = true;
     for (int s = 0; s < d->nseg; ++s)
-        fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == d->compute && (p.seg[s].C % (kce / 4)) == 0;
+        fast = fast && p.seg[s].vec_ok &&
+               ((p.seg[s].dtype == d->compute && (p.seg[s].C % (kce / 4)) == 0) ||
+                (d->compute == DSVC_BF16 && p.seg[s].dtype == DSVC_F32 && (p.seg[s].C % 4) == 0 && !d->s2d));   // converted while staged
 
     // ---- bf16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
     DsvcOptions opt = g_dsvc_opt;
-    if (p.s2d) {                            // only the general kernel's staging understands the space-to-depth view
-        DSVC_REQUIRE(fast, "conv2d: s2d needs the vector staging path");
+    if (p.s2d || per_item) {                // only the general kernel's staging understands the space-to-depth view / item offsets
+        DSVC_REQUIRE(fast, "conv2d: s2d and batch_inner need the vector staging path (16-byte aligned rows, whole 4/8-channel quarters)");
         opt.specialised = 0;
     }
     if (p.post_w) {                          // fused trailing 1x1 conv: only the two-group 3x3 kernel implements it

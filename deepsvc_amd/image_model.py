@@ -86,10 +86,17 @@ class _ScanPlan:
         Nc, Mc, d = codec.N, codec.M, codec.slice_depth          # hyper-latent z: N channels; latent y: M channels
         self.device, self.epoch, self.graphs = device, -1, {}
         act = lambda H, W, C: ops.new_act(B, H, W, C, F32, device)
-        self.y, self.y_hat, self.means, self.scales = act(h, w, Mc), act(h, w, Mc), act(h, w, Mc), act(h, w, Mc)
+        self.y, self.y_hat = act(h, w, Mc), act(h, w, Mc)
+        # (means, scales) and every slice's (mu_i, sigma_i) sit in ONE buffer each, pair after pair: the mean and the scale
+        # stack of a scan level run as batch items of single launches (ops.conv2d items=...), which read / write them at a
+        # fixed item stride
+        self.pair = ops.new_act(2 * B, h, w, Mc, F32, device)
+        self.means, self.scales = ops.Act(self.pair.buf[:B]), ops.Act(self.pair.buf[B:])
         self.z_hat = act(h // 4, w // 4, Nc)
-        self.mus = [act(h, w, d) for _ in range(codec.num_slices)]
-        self.scs = [act(h, w, d) for _ in range(codec.num_slices)]
+        self.musc = ops.new_act(2 * B * codec.num_slices, h, w, d, F32, device)
+        self.mus = [ops.Act(self.musc.buf[2 * i * B:(2 * i + 1) * B]) for i in range(codec.num_slices)]
+        self.scs = [ops.Act(self.musc.buf[(2 * i + 1) * B:(2 * i + 2) * B]) for i in range(codec.num_slices)]
+        self.B = B
         self.nz, self.ny, self.ns = B * Nc * (h // 4) * (w // 4), B * Mc * h * w, B * d * h * w
         k = codec.max_support_slices
         self.groups = [[i] for i in range(min(k, codec.num_slices))] + \
@@ -225,8 +232,41 @@ class ChannelSplitICIP2020ResB(nn.Module):
             lambda: self._stack(self.cc_mean_transforms[i], self._support(means, y_hat, i), out=mu_out),
             lambda: self._stack(self.cc_scale_transforms[i], self._support(scales, y_hat, i), out=sc_out)])
 
+    def _item_stacks(self, group, segC, device):
+        """Per layer, the packed weights of the 2*len(group) mean / scale stacks of one dependency level, item order
+        (mean_i, scale_i) for i in group.  Rebuilt (and this codec's graphs invalidated) when a layer has been repacked."""
+        stacks = [[m for m in st[i] if isinstance(m, Conv2d)] for i in group for st in (self.cc_mean_transforms, self.cc_scale_transforms)]
+        cache = self.__dict__.setdefault("_item_cache", {})
+        key = (tuple(group), tuple(segC), ops.RT.compute, str(device))
+        out = []
+        for l in range(len(stacks[0])):
+            packs = [st[l]._packed(list(segC) if l == 0 else [st[l].in_channels], device) for st in stacks]
+            ipc = cache.get(key + (l,))
+            if ipc is None or any(a is not b for a, b in zip(ipc.sources, packs)):
+                ipc = cache[key + (l,)] = ops.ItemPackedConv(packs)
+                self._epoch_ref()[0] += 1
+            out.append(ipc)
+        return out
+
     def _group_params(self, ws, group):
-        """mu_i, sigma_i for every slice of one dependency level: 2*len(group) independent 4-conv stacks, one flat fork."""
+        """mu_i, sigma_i for every slice of one dependency level: 2*len(group) independent 4-conv stacks over the same
+        support.  With one image in flight they run as the batch items of ONE launch per layer (include/dsvc.h: batch_inner)
+        -- a level costs 4 small launches instead of 8..32; the launches are latency-bound, so the items are free."""
+        k = min(group[0], self.max_support_slices)
+        segs = self._support(ws.means, ws.y_hat, group[0])
+        if ops.ITEM_SCAN[0] and ws.B == 1 and ops.items_ok(segs + [ws.scales]) and \
+                all(min(i, self.max_support_slices) == k for i in group) and group == list(range(group[0], group[0] + len(group))):
+            G, img = 2 * len(group), ws.means.npix * ws.means.ld * 4
+            ipcs = self._item_stacks(group, [a.C for a in segs], ws.device)
+            hidden, slope = self._stack_act
+            x = ops.conv2d(ipcs[0], segs, act=hidden, slope=slope, out_dtype=ops.RT.storage,
+                           items=(2, [(img, 0)] + [(0, 0)] * (len(segs) - 1)))           # item b: means|scales = b % 2, shared support
+            for ipc in ipcs[1:-1]:
+                x = ops.conv2d(ipc, [x], act=hidden, slope=slope, out_dtype=ops.RT.storage,
+                               items=(G, [(x.H * x.W * x.ld * x.buf.element_size(), 0)]))
+            out = ops.Act(ws.musc.buf[2 * group[0]:2 * group[0] + G])
+            ops.conv2d(ipcs[-1], [x], out, out_dtype=F32, items=(G, [(x.H * x.W * x.ld * x.buf.element_size(), 0)]))
+            return
         fns = []
         for i in group:
             fns.append(lambda i=i: self._stack(self.cc_mean_transforms[i], self._support(ws.means, ws.y_hat, i), out=ws.mus[i]))

@@ -57,6 +57,7 @@ def _stream():
 import threading as _threading
 
 _fork_pools = _threading.local()
+ITEM_SCAN = [_os.environ.get("DSVC_NO_ITEM_SCAN", "0") != "1"]   # mean+scale stacks of a scan level as one launch per layer
 FUSE_1X1 = [_os.environ.get("DSVC_NO_FUSE_1X1", "") == ""]   # ResBottleneck conv2 -> act -> conv3 -> + x in one launch (bf16, 64 ch)
 S2D = [_os.environ.get("DSVC_NO_S2D", "") == ""]       # conv5x5/s2 through the space-to-depth view (bf16 mode)
 USE_FORKS = [_os.environ.get("DSVC_FORKS", "") != ""]   # opt-in: measured 17.15 vs 17.6 fps (event edges cost more than the overlap)
@@ -211,6 +212,22 @@ class PackedConv:
         PACK_EPOCH[0] += 1
 
 
+class ItemPackedConv:
+    """Packed weights of G convs of identical shape, item after item, for one launch that runs them side by side as the
+    batch items of include/dsvc.h's `batch_inner` mode (the slice scan's mean / scale stacks)."""
+
+    def __init__(self, packs):
+        p0 = packs[0]
+        sig = lambda p: (p.Cout, p.kh, p.kw, p.segC, p.stride, p.pad, p.compute, p.s2d, p.weight.numel(), p.bias is None)
+        assert all(sig(p) == sig(p0) for p in packs) and not p0.s2d and p0.weight.numel() % 16 == 0
+        self.items, self.sources = len(packs), tuple(packs)
+        self.Cout, self.kh, self.kw, self.segC = p0.Cout, p0.kh, p0.kw, p0.segC
+        self.stride, self.pad, self.compute, self.s2d = p0.stride, p0.pad, p0.compute, False
+        self.weight = torch.cat([p.weight for p in packs])
+        self.weight_stride = p0.weight.numel()
+        self.bias = None if p0.bias is None else torch.stack([p.bias for p in packs]).contiguous()
+
+
 def s2d_weights(w5, seg_channels, V):
     """[Cout, Cin, 5, 5] weights of a stride-2 pad-2 conv -> [Cout, 4*Cin, 3, 3] weights of the equivalent stride-1 pad-1
     conv over the space-to-depth view of include/dsvc.h (view channel g*4V + (2*py+px)*V + c = channel g*V + c of image
@@ -253,9 +270,13 @@ PROFILE = None
 
 
 def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.01, res1=None, gate=None, res2=None,
-           shuffle=1, out_dtype=None, post=None):
-    """Run one fused conv.  inputs: list of Act (virtual torch.cat along channels)."""
+           shuffle=1, out_dtype=None, post=None, items=None):
+    """Run one fused conv.  inputs: list of Act (virtual torch.cat along channels).
+    items=(inner, [(stride_lo, stride_hi) per input, bytes]) with an ItemPackedConv `pc`: pc.items independent convs in one
+    launch (include/dsvc.h: batch_inner); every input Act is item 0's image, the output is a dense [items, H, W, C] Act."""
     x0 = inputs[0]
+    if items is not None:
+        return _conv2d_items(pc, inputs, out, items, act=act, pre_act=pre_act, slope=slope, res1=res1, shuffle=shuffle, out_dtype=out_dtype)
     _require_gpu(x0.buf)
     s2d = getattr(pc, "s2d", False)
     mult = 4 if s2d else 1
@@ -309,6 +330,50 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
         return out
     N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
     return out
+
+
+def _conv2d_items(pc, inputs, out, items, *, act, pre_act, slope, res1, shuffle, out_dtype):
+    inner, strides = items
+    x0 = inputs[0]
+    _require_gpu(x0.buf)
+    assert isinstance(pc, ItemPackedConv) and tuple(a.C for a in inputs) == pc.segC and len(strides) == len(inputs) and inner >= 1
+    G, H, W = pc.items, x0.H, x0.W
+    Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.kw) // pc.stride + 1
+    oshape = (G, Ho * shuffle, Wo * shuffle, pc.Cout // (shuffle * shuffle))
+    if out is None:
+        out = new_act(*oshape, out_dtype, x0.device)
+    assert (out.B, out.H, out.W, out.C) == oshape, f"out shape {(out.B, out.H, out.W, out.C)} != {oshape}"
+    d = N.ConvDesc()
+    d.B, d.H, d.W, d.nseg = G, H, W, len(inputs)
+    for i, (a, (lo, hi)) in enumerate(zip(inputs, strides)):
+        assert (a.H, a.W) == (H, W)
+        d.seg[i].ptr, d.seg[i].C, d.seg[i].ld, d.seg[i].dtype = a.ptr, a.C, a.ld, a.code
+        d.in_bstride[i][0], d.in_bstride[i][1] = lo, hi
+    d.batch_inner, d.weight_bstride, d.bias_bstride = inner, pc.weight_stride, pc.Cout
+    d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, pc.stride, pc.pad
+    d.Cout, d.compute = pc.Cout, pc.compute
+    d.weight = pc.weight.data_ptr()
+    d.bias = None if pc.bias is None else pc.bias.data_ptr()
+    d.pre_act, d.act, d.slope = pre_act, act, slope
+    if res1 is not None:
+        assert (res1.B, res1.H, res1.W, res1.C) == oshape
+        d.res1, d.res1_ld, d.res1_dtype = res1.ptr, res1.ld, res1.code
+    d.shuffle = shuffle
+    d.out, d.out_ld, d.out_dtype = out.ptr, out.ld, out.code
+    N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d (items)")
+    return out
+
+
+def items_ok(acts):
+    """Can these inputs feed the vector staging path that include/dsvc.h's batch_inner mode needs?"""
+    for a in acts:
+        es = a.buf.element_size()
+        same = a.code == RT.compute
+        q = (8 if RT.compute == N.BF16 else 2) if same else 4
+        if a.ptr % 16 or (a.ld * es) % 16 or a.C % q or not (same or (RT.compute == N.BF16 and a.dtype == torch.float32)):
+            return False
+    return True
 
 
 # --------------------------------------------------------------------------------------------

@@ -104,6 +104,15 @@ typedef struct dsvc_conv_desc {
      * Supported where the two-group 3x3 kernel applies (bf16, 64 -> 64 channels, >= 1024 tiles, bf16 NHWC in/out/res1,
      * no res2 / gate / shuffle); dsvc_conv2d fails with DSVC_E_ARG otherwise -- callers fuse only then. */
     const void* post_weight; const float* post_bias;
+    /* batch_inner > 0: the B batch items are INDEPENDENT convs of identical shape in one launch (the slice scan runs the
+     * mean and the scale stack of a slice -- image_model.py:168-176,227-237 -- side by side).  Item b uses the packed
+     * weights at weight + b * weight_bstride bytes and the bias at bias + b * bias_bstride floats, and reads input segment s at
+     *     in[s].ptr + (b % batch_inner) * in_bstride[s][0] + (b / batch_inner) * in_bstride[s][1]      (bytes; 0 = shared by the items)
+     * instead of the dense batch layout.  Outputs and residuals keep the dense [B, H, W, ld] layout.  Needs the vector
+     * staging path (16-byte aligned rows); excludes s2d, post_weight and res1_scale.  0 = an ordinary batch. */
+    int32_t batch_inner;
+    int64_t weight_bstride, bias_bstride;
+    int64_t in_bstride[3][2];
 } dsvc_conv_desc;
 
 /* bytes of the packed weight buffer for a conv with these input segments */

@@ -33,6 +33,24 @@ def test_library_exports_every_declared_symbol():
     assert L.dsvc_version() == 1
 
 
+def test_conv_desc_ctypes_mirror_matches_the_header(tmp_path):
+    """The ctypes mirror of dsvc_conv_desc must lay out exactly like the C struct: offsets and size from gcc against ctypes."""
+    import ctypes
+    import subprocess
+    fields = [n for n, _ in N.ConvDesc._fields_]
+    cname = {"seg": "in"}
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dsvc.h"\nint main(void){\n' +
+                   "".join(f'printf("%zu\\n", offsetof(dsvc_conv_desc, {cname.get(f, f)}));\n' for f in fields) +
+                   'printf("%zu\\n", sizeof(dsvc_conv_desc)); printf("%zu\\n", sizeof(dsvc_seg)); return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    nums = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    for f, off in zip(fields, nums):
+        assert getattr(N.ConvDesc, f).offset == off, f"dsvc_conv_desc.{f}: ctypes offset {getattr(N.ConvDesc, f).offset} != C {off}"
+    assert ctypes.sizeof(N.ConvDesc) == nums[len(fields)] and ctypes.sizeof(N.Seg) == nums[len(fields) + 1]
+
+
 def test_cpu_tensors_are_refused():
     from deepsvc_amd.modules import Conv2d, torch_warp
     with pytest.raises(N.NativeError):

@@ -273,6 +273,35 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
     report_close("direct vs torch", got, want, 2e-2 if out_dt == "bf16" else 5e-3, tol)
 
 
+@pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,pre,act", [
+    ((96, 48), ("f32", "f32"), 96, 1, 68, 120, 0, 3),                 # cc_mean/cc_scale first layer
+    ((96, 36), ("f32", "f32"), 96, 1, 68, 120, 0, 3),                 # 36 = 32 + a half-filled quarter (C % 8 == 4)
+    ((64, 12, 8), ("f32", "f32", "bf16"), 64, 2, 33, 70, 2, 2),       # mixed storage, short chunks, LeakyReLU on the way in
+    ((4,), ("f32",), 32, 1, 40, 50, 1, 0),                            # a single half quarter
+])
+def test_conv_fp32_storage_converted_while_staged(segs, seg_dt, cout, B, H, W, pre, act):
+    """bf16 compute over fp32 storage (the slice scan's fp32 latents): the general kernel converts while staging --
+    two batched 16-B loads per 8-channel quarter, RNE to bf16 -- instead of the per-element path.  Against torch on
+    bf16-rounded operands, including segments whose channel count is 4 mod 8 and a fused leading activation."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) * 3 + cout + W)
+    bf = torch.bfloat16
+    dts = {"f32": torch.float32, "bf16": bf}
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        ins = [_act(x, dts[t]) for x, t in zip(xs, seg_dt)]
+        got = m.run(ins if len(ins) > 1 else ins[0], out_dtype=torch.float32, pre_act=pre, act=act, slope=0.05).nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    xb = torch.cat([_torch_act(x.to(bf).float() if t == "bf16" else x, pre, 0.05).to(bf).float() for x, t in zip(xs, seg_dt)], 1)
+    want = _torch_act(F.conv2d(xb, w, b, padding=1), act, 0.05)
+    report_close("converted staging vs torch", got, want, 5e-3, 5e-3 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("segs,cout,B,H,W", [((8, 64, 8), 96, 1, 64, 96), ((8,), 64, 2, 128, 160), ((8, 64, 8), 96, 1, 272, 480),
                                              ((16, 8), 192, 1, 34, 62), ((8,), 192, 1, 64, 64)])
 def test_conv5x5s2_space_to_depth_view(segs, cout, B, H, W):

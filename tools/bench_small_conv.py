@@ -10,6 +10,9 @@ SHAPES = [  # (name, segs, seg dtypes, cout, H, W, act, out dtype)
     ("64->64 gelu", (64,), ("bf16",), 64, 68, 120, N.ACT_GELU, "bf16"),
     ("96->64 gelu", (96,), ("bf16",), 64, 68, 120, N.ACT_GELU, "bf16"),
     ("96+48(f32)->96 gelu", (96, 48), ("f32", "f32"), 96, 68, 120, N.ACT_GELU, "bf16"),
+    ("64+32(f32)->64 gelu", (64, 32), ("f32", "f32"), 64, 68, 120, N.ACT_GELU, "bf16"),
+    ("96+48+16(f32,f32,bf16)->96 gelu", (96, 48, 16), ("f32", "f32", "bf16"), 96, 68, 120, N.ACT_GELU, "bf16"),
+    ("96+36(f32)->96 gelu", (96, 36), ("f32", "f32"), 96, 68, 120, N.ACT_GELU, "bf16"),
     ("32->12 f32out", (32,), ("bf16",), 12, 68, 120, N.ACT_NONE, "f32"),
     ("64->32 none", (64,), ("bf16",), 32, 68, 120, N.ACT_NONE, "bf16"),
     ("64->64 @136x240", (64,), ("bf16",), 64, 136, 240, N.ACT_LRELU, "bf16"),
