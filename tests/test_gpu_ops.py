@@ -468,8 +468,17 @@ def test_resampling_and_layout_ops():
     report_close("avgpool", ops.pool2x2(_act(x), "avg").nchw().cpu(), F.avg_pool2d(x, 2, 2), 1e-6, 1e-6)
     x = torch.randn(2, 32, 6, 10)
     report_close("maxpool", ops.pool2x2(_act(x), "max").nchw().cpu(), F.max_pool2d(x, 2, 2), 0, 0)
+    for C, dt in ((64, torch.bfloat16), (16, torch.bfloat16), (8, torch.float32), (64, torch.float32)):     # 16 bytes per thread
+        x = torch.randn(2, C, 6, 10).to(dt).float()
+        for mode, ref in (("avg", F.avg_pool2d), ("max", F.max_pool2d)):
+            report_close(f"{mode}pool vec {C} {dt}", ops.pool2x2(_act(x, dt), mode).nchw().float().cpu(), ref(x, 2, 2).to(dt).float(), 1e-2 if dt == torch.bfloat16 else 1e-6, 2e-2 if dt == torch.bfloat16 else 1e-6)
     x = torch.randn(2, 64, 5, 6)
     report_close("pixel_shuffle4", ops.pixel_shuffle_nchw(x.to(DEV), 4, dtype=torch.float32).nchw().cpu(), F.pixel_shuffle(x, 4), 0, 0)
+    for shape, r in (((2, 256, 5, 70), 4), ((1, 32, 7, 9), 2), ((1, 128, 3, 130), 4)):      # Co % 8 == 0: one thread per pixel x 8 channels
+        x = torch.randn(*shape)
+        report_close(f"pixel_shuffle{r} vec8 f32", ops.pixel_shuffle_nchw(x.to(DEV), r, dtype=torch.float32).nchw().cpu(), F.pixel_shuffle(x, r), 0, 0)
+        report_close(f"pixel_shuffle{r} vec8 bf16", ops.pixel_shuffle_nchw(x.to(DEV), r, dtype=torch.bfloat16).nchw().cpu(),
+                     F.pixel_shuffle(x, r).to(torch.bfloat16).float(), 0, 0)
     x = torch.randn(2, 37, 9, 11)       # NCHW-contiguous input goes through the transpose kernel
     a = ops.to_act(x.to(DEV))
     assert torch.equal(a.buf.cpu(), x.permute(0, 2, 3, 1).contiguous())
