@@ -56,7 +56,26 @@ def apply_calibration(state_dict, calib):
     return out
 
 
-def make_model(weight_set="W0", calibrated=True):
+# BASELINE.json config 3 asks for four operating points standing in for lambda in {256, 512, 1024, 2048}.  The calibrated
+# sets are the 2048 ("PSNR model") point; a lower point scales the latent y of both codecs down by this gain (last analysis
+# conv) and the first synthesis conv's weight up by its inverse -- coarser effective quantisation, fewer bits, lower PSNR.
+RATE_GAINS = {2048: 1.0, 1024: 0.7, 512: 0.5, 256: 0.35}
+
+
+def apply_rate_point(state_dict, lam, codecs=("mv_codec.", "res_codec.")):
+    g = RATE_GAINS[lam]
+    if g == 1.0:
+        return state_dict
+    out = dict(state_dict)
+    for pre in codecs:
+        last = max(int(k[len(pre) + 4:].split(".")[0]) for k in out if k.startswith(pre + "g_a."))
+        for leaf in ("weight", "bias"):
+            out[f"{pre}g_a.{last}.{leaf}"] = out[f"{pre}g_a.{last}.{leaf}"] * g
+        out[f"{pre}g_s.0.weight"] = out[f"{pre}g_s.0.weight"] / g
+    return out
+
+
+def make_model(weight_set="W0", calibrated=True, lam=2048):
     """Product `DeepSVC` on the CPU with the named synthetic weight set loaded (move it with .to(device))."""
     from .video_model import DeepSVC
     seed = {"W0": 0, "W1": 1}[weight_set]
@@ -65,7 +84,7 @@ def make_model(weight_set="W0", calibrated=True):
     model = DeepSVC()
     torch.random.set_rng_state(rng)
     if calibrated:
-        sd = apply_calibration(model.state_dict(), load_calibration())
+        sd = apply_rate_point(apply_calibration(model.state_dict(), load_calibration()), lam)
         with torch.no_grad():
             for k, v in model.state_dict().items():
                 v.copy_(sd[k])
@@ -73,7 +92,7 @@ def make_model(weight_set="W0", calibrated=True):
     return model
 
 
-def make_icodec(weight_set="W0", calibrated=True):
+def make_icodec(weight_set="W0", calibrated=True, lam=2048):
     """Product `ICIP2020ResB` (I-frame codec) on the CPU with the named synthetic weight set: seeded default init x the
     multipliers of deepsvc_amd/data/icip_w0_calibration.json (tools/calibrate_icip.py)."""
     from .image_model import ICIP2020ResB
@@ -83,7 +102,7 @@ def make_icodec(weight_set="W0", calibrated=True):
     model = ICIP2020ResB()
     torch.random.set_rng_state(rng)
     if calibrated:
-        sd = apply_calibration(model.state_dict(), load_calibration(ICIP_CALIBRATION))
+        sd = apply_rate_point(apply_calibration(model.state_dict(), load_calibration(ICIP_CALIBRATION)), lam, codecs=("",))
         with torch.no_grad():
             for k, v in model.state_dict().items():
                 v.copy_(sd[k])

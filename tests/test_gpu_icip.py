@@ -123,3 +123,55 @@ def test_gop_with_intra_coded_key_frame():
         assert table.shape == (4, len(harness.METRIC_COLUMNS))
     finally:
         ops.set_precision("fp32")
+
+
+def test_config3_gop12_four_rate_points():
+    """BASELINE.json config 3: GOP = 12 with an intra-coded key frame at four operating points (synthetic stand-ins for
+    lambda in {256, 512, 1024, 2048}: synth.RATE_GAINS).  Properties the domain offers without the reference: every frame
+    decodes, the rate grows with lambda for the I-frame and for the P-frames, and so does the key frame's PSNR."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("bf16")
+    try:
+        size, gop = 192, 12
+        frames = [f.to(DEV) for f in synth.make_frames(size, size, gop)]
+        sms = [None] + [synth.make_sm_fea(size, size, t).to(DEV) for t in range(1, gop)]
+        points = []
+        for lam in (256, 512, 1024, 2048):
+            i_model = synth.make_icodec("W0", lam=lam); i_model.update(force=True); i_model = i_model.to(DEV)
+            p_model = synth.make_model("W0", lam=lam); p_model.update(force=True); p_model = p_model.to(DEV)
+            rows = harness.code_gop(p_model, frames, sms, unit=0, sync=torch.cuda.synchronize, i_model=i_model)
+            assert len(rows) == gop and all(np.isfinite(v) for r in rows for v in r)
+            i_bpp, i_psnr = rows[0][3], rows[0][4]
+            p_bpp = float(np.mean([r[2] + r[3] for r in rows[1:]]))
+            points.append((lam, i_bpp, i_psnr, p_bpp, float(np.mean([r[4] for r in rows[1:]]))))
+            print(f"lambda {lam}: I {i_bpp:.3f} bpp {i_psnr:.2f} dB | P mean {p_bpp:.3f} bpp {points[-1][4]:.2f} dB")
+        for lo, hi in zip(points[:-1], points[1:]):
+            assert hi[1] > lo[1] and hi[3] > lo[3], f"rate not increasing with lambda: {lo} -> {hi}"
+            assert hi[2] > lo[2] - 0.05, f"key-frame PSNR not increasing with lambda: {lo} -> {hi}"
+    finally:
+        ops.set_precision("fp32")
+
+
+def test_low_rate_point_parity_with_oracle():
+    """The lambda = 256 stand-in through the real bitstream path in fp32 mode against the oracle on the same weights
+    (P-frame codec, 64 x 64): bytes within 1 %, PSNR within 0.05 dB -- the north_star tolerances at another operating point."""
+    from deepsvc_amd import ops, synth
+    from oracle.codec import DeepSVCOracle, strings_nbytes
+    ops.set_precision("fp32")
+    m = synth.make_model("W0", lam=256)
+    m.update(force=True)
+    orc = DeepSVCOracle(m.state_dict())
+    orc.update(force=True)
+    m = m.to(DEV)
+    fr = synth.make_frames(64, 64, 2)
+    sm = synth.make_sm_fea(64, 64, 1)
+    mv_g, res_g = m.compress(fr[0].to(DEV), fr[1].to(DEV), sm.to(DEV), None)
+    dec_g = m.decompress(fr[0].to(DEV), mv_g, res_g, sm.to(DEV), None)
+    mv_o, res_o = orc.compress(fr[0], fr[1], sm, None)
+    dec_o = orc.decompress(fr[0], mv_o, res_o, sm, None)
+    bg, bo = strings_nbytes(mv_g) + strings_nbytes(res_g), strings_nbytes(mv_o) + strings_nbytes(res_o)
+    print(f"lambda 256, 64x64: bytes gpu {bg} oracle {bo}; identical y strings: mv {mv_g['strings'][0][0] == mv_o['strings'][0][0]}, "
+          f"res {res_g['strings'][0][0] == res_o['strings'][0][0]}")
+    assert abs(bg - bo) <= max(0.01 * bo, 8)
+    assert abs(psnr(dec_g[1].cpu(), fr[1]) - psnr(dec_o[1], fr[1])) <= 0.05
+    assert psnr(dec_g[1].cpu(), dec_o[1]) > 40
