@@ -57,10 +57,11 @@ static inline uint64_t div_by(uint64_t x, uint32_t freq) {
 }
 
 struct Encoder {
-    std::vector<uint32_t> items;   // start | (range-1) << 16
-    std::vector<uint8_t> bypass;   // 1 when the item is a bypass nibble
-    std::vector<uint32_t> words;   // scratch for flush()
-    int64_t nbytes = -1;           // valid after a size query
+    std::vector<uint32_t> items;       // start | (range-1) << 16; only the first `count` entries are live
+    size_t count = 0;
+    std::vector<uint64_t> bypass_at;   // ascending positions of the items that are bypass nibbles (escapes are rare)
+    std::vector<uint32_t> words;       // scratch for flush()
+    int64_t nbytes = -1;               // valid after a size query
     int64_t first = 0;
 };
 
@@ -83,9 +84,9 @@ struct Decoder {
     }
 };
 
-inline void push(Encoder* e, uint32_t start, uint32_t range, bool bp) {
-    e->items.push_back((start & 0xFFFFu) | ((range - 1) << 16));
-    e->bypass.push_back(bp ? 1 : 0);
+inline void push_bypass(Encoder* e, uint32_t nibble) {      // caller guarantees capacity
+    e->bypass_at.push_back((uint64_t)e->count);
+    e->items[e->count++] = nibble;
 }
 
 bool table_ok(const dsvc_cdf_table* t) {
@@ -108,30 +109,47 @@ extern "C" int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, 
     DSVC_REQUIRE(table_ok(t), "rans_encode: bad cdf table");
     Encoder* e = (Encoder*)enc;
     e->nbytes = -1;
-    e->items.reserve(e->items.size() + (size_t)n + 64);
-    e->bypass.reserve(e->bypass.size() + (size_t)n + 64);
+    // validation hoisted out of the symbol loop: the table once, the indexes in one vectorisable pass
+    for (int r = 0; r < t->rows; ++r) {
+        const int32_t max_value = t->cdf_length[r] - 2;
+        DSVC_REQUIRE(max_value >= 0 && max_value + 1 < t->stride, "rans_encode: cdf_length[%d] invalid", r);
+    }
+    {
+        uint32_t worst = 0;
+        for (int64_t i = 0; i < n; ++i) worst |= (uint32_t)indexes[i] >= (uint32_t)t->rows ? 1u : 0u;
+        if (worst)
+            for (int64_t i = 0; i < n; ++i)
+                DSVC_REQUIRE(indexes[i] >= 0 && indexes[i] < t->rows, "rans_encode: cdf index %d out of range at %lld", indexes[i], (long long)i);
+    }
+    constexpr size_t kSlack = 32;     // an escape appends at most 1 + 2 + 8 bypass items after its symbol
+    if (e->items.size() < e->count + (size_t)n + kSlack) e->items.resize(e->count + (size_t)n + (size_t)n / 8 + 4 * kSlack);
+    const int32_t* cdf = t->cdf;
+    const int64_t stride = t->stride;
     for (int64_t i = 0; i < n; ++i) {
         const int32_t ci = indexes[i];
-        DSVC_REQUIRE(ci >= 0 && ci < t->rows, "rans_encode: cdf index %d out of range at %lld", ci, (long long)i);
-        const int32_t* row = t->cdf + (int64_t)ci * t->stride;
+        const int32_t* row = cdf + (int64_t)ci * stride;
         const int32_t max_value = t->cdf_length[ci] - 2;
-        DSVC_REQUIRE(max_value >= 0 && max_value + 1 < t->stride, "rans_encode: cdf_length[%d] invalid", ci);
         int32_t v = symbols[i] - t->offset[ci];
-        uint32_t raw = 0;
-        if (v < 0) { raw = (uint32_t)(-2 * (int64_t)v - 1); v = max_value; }
-        else if (v >= max_value) { raw = (uint32_t)(2 * (int64_t)(v - max_value)); v = max_value; }
-        push(e, (uint32_t)row[v], (uint32_t)(row[v + 1] - row[v]), false);
-        if (v == max_value) {
-            int32_t nb = 0;
-            while (nb < 8 && (raw >> (nb * kBypassBits)) != 0) ++nb;
-            int32_t val = nb;
-            while (val >= kBypassMax) { push(e, kBypassMax, kBypassMax + 1, true); val -= kBypassMax; }
-            push(e, (uint32_t)val, (uint32_t)val + 1, true);
-            for (int32_t j = 0; j < nb; ++j) {
-                const uint32_t nib = (raw >> (j * kBypassBits)) & kBypassMax;
-                push(e, nib, nib + 1, true);
-            }
+        if (__builtin_expect((uint32_t)v < (uint32_t)max_value, 1)) {       // in-range symbol: one item, no escape
+            const uint32_t start = (uint32_t)row[v];
+            e->items[e->count++] = (start & 0xFFFFu) | (((uint32_t)row[v + 1] - start - 1u) << 16);
+            continue;
         }
+        uint32_t raw;
+        if (v < 0) raw = (uint32_t)(-2 * (int64_t)v - 1);
+        else raw = (uint32_t)(2 * (int64_t)(v - max_value));
+        v = max_value;
+        if (e->items.size() < e->count + (size_t)(n - i) + kSlack) e->items.resize(e->items.size() + (size_t)n / 8 + 4 * kSlack);
+        {
+            const uint32_t start = (uint32_t)row[v];
+            e->items[e->count++] = (start & 0xFFFFu) | (((uint32_t)row[v + 1] - start - 1u) << 16);
+        }
+        int32_t nb = 0;
+        while (nb < 8 && (raw >> (nb * kBypassBits)) != 0) ++nb;
+        int32_t val = nb;
+        while (val >= kBypassMax) { push_bypass(e, kBypassMax); val -= kBypassMax; }
+        push_bypass(e, (uint32_t)val);
+        for (int32_t j = 0; j < nb; ++j) push_bypass(e, (raw >> (j * kBypassBits)) & kBypassMax);
     }
     return DSVC_OK;
 }
@@ -140,28 +158,38 @@ extern "C" int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap) {
     if (!enc) { dsvc_set_error("rans_flush: null encoder"); return DSVC_E_ARG; }
     Encoder* e = (Encoder*)enc;
     if (e->nbytes < 0) {
-        const size_t m = e->items.size();
-        e->words.assign(m + 4, 0u);  // every item emits at most one word; +2 state words
+        const size_t m = e->count;
+        e->words.resize(m + 4);      // every item emits at most one word; +2 state words (+1: the speculative store below)
+        uint32_t* words = e->words.data();
+        const uint32_t* items = e->items.data();
         size_t p = e->words.size();
         uint64_t x = kRansL;
+        size_t nbp = e->bypass_at.size();
+        uint64_t next_bp = nbp ? e->bypass_at[nbp - 1] : ~0ull;
         for (size_t k = m; k-- > 0;) {
-            const uint32_t it = e->items[k];
-            const uint32_t start = it & 0xFFFFu;
-            if (!e->bypass[k]) {
-                const uint32_t freq = (it >> 16) + 1;
+            const uint32_t it = items[k];
+            if (__builtin_expect((uint64_t)k != next_bp, 1)) {
+                const uint32_t start = it & 0xFFFFu, freq = (it >> 16) + 1;
                 const uint64_t x_max = ((kRansL >> kPrecision) << 32) * (uint64_t)freq;
-                if (x >= x_max) { e->words[--p] = (uint32_t)x; x >>= 32; }
+                // renormalise without a branch (a word leaves every ~32/bits symbols: badly predictable): the word is stored
+                // speculatively below the write pointer and the pointer moves only when it counts
+                const bool emit = x >= x_max;
+                words[p - 1] = (uint32_t)x;
+                p -= emit ? 1 : 0;
+                x = emit ? x >> 32 : x;
                 const uint64_t q = div_by(x, freq);                           // x / freq without a divide
                 x = x + start + q * (uint64_t)((1u << kPrecision) - freq);     // == (q << 16) + x % freq + start
             } else {
+                --nbp;
+                next_bp = nbp ? e->bypass_at[nbp - 1] : ~0ull;
                 const uint64_t x_max = ((kRansL >> 16) << 32) * (1ull << (16 - kBypassBits));
-                if (x >= x_max) { e->words[--p] = (uint32_t)x; x >>= 32; }
-                x = (x << kBypassBits) | start;
+                if (x >= x_max) { words[--p] = (uint32_t)x; x >>= 32; }
+                x = (x << kBypassBits) | (it & 0xFFFFu);
             }
         }
         p -= 2;
-        e->words[p] = (uint32_t)x;
-        e->words[p + 1] = (uint32_t)(x >> 32);
+        words[p] = (uint32_t)x;
+        words[p + 1] = (uint32_t)(x >> 32);
         e->first = (int64_t)p;
         e->nbytes = (int64_t)(e->words.size() - p) * 4;
     }
@@ -169,7 +197,7 @@ extern "C" int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap) {
     if (cap < e->nbytes) { dsvc_set_error("rans_flush: buffer %lld < %lld", (long long)cap, (long long)e->nbytes); return DSVC_E_RANGE; }
     std::memcpy(out, e->words.data() + e->first, (size_t)e->nbytes);  // x86-64: little endian == stream order
     const int64_t nb = e->nbytes;
-    e->items.clear(); e->bypass.clear(); e->nbytes = -1;
+    e->count = 0; e->bypass_at.clear(); e->nbytes = -1;
     return nb;
 }
 
@@ -206,14 +234,27 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
     DSVC_REQUIRE(dec && indexes && out && n >= 0, "rans_decode: null argument");
     DSVC_REQUIRE(table_ok(t), "rans_decode: bad cdf table");
     Decoder* d = (Decoder*)dec;
+    {   // validation hoisted out of the symbol loop
+        uint32_t worst = 0;
+        for (int64_t i = 0; i < n; ++i) worst |= (uint32_t)indexes[i] >= (uint32_t)t->rows ? 1u : 0u;
+        if (worst)
+            for (int64_t i = 0; i < n; ++i)
+                DSVC_REQUIRE(indexes[i] >= 0 && indexes[i] < t->rows, "rans_decode: cdf index %d out of range at %lld", indexes[i], (long long)i);
+        for (int r = 0; r < t->rows; ++r)
+            DSVC_REQUIRE(t->cdf_length[r] >= 2 && t->cdf_length[r] <= t->stride, "rans_decode: cdf_length[%d] invalid", r);
+    }
     const uint16_t* lut = t->lut;
+    const int32_t* cdf = t->cdf;
+    const int64_t stride = t->stride;
+    const uint32_t* words = d->words.data();
+    const size_t nw = d->words.size();
+    uint64_t x = d->x;
+    size_t pos = d->pos;
     for (int64_t i = 0; i < n; ++i) {
         const int32_t ci = indexes[i];
-        DSVC_REQUIRE(ci >= 0 && ci < t->rows, "rans_decode: cdf index %d out of range at %lld", ci, (long long)i);
-        const int32_t* row = t->cdf + (int64_t)ci * t->stride;
-        const int32_t len = t->cdf_length[ci];
-        const int32_t max_value = len - 2;
-        const uint32_t cf = (uint32_t)(d->x & 0xFFFFu);
+        const int32_t* row = cdf + (int64_t)ci * stride;
+        const int32_t max_value = t->cdf_length[ci] - 2;
+        const uint32_t cf = (uint32_t)(x & 0xFFFFu);
         // largest s in [0, len-2] with row[s] <= cf  (row[0] = 0, row[len-1] = 65536 > cf):
         // start from the LUT's answer for the bucket's first value, scan forward (usually 0-1 steps)
         int32_t s;
@@ -221,7 +262,7 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
             s = lut[(size_t)ci * 256 + (cf >> 8)];
             while ((uint32_t)row[s + 1] <= cf) ++s;
         } else {
-            int32_t lo = 0, hi = len - 1;
+            int32_t lo = 0, hi = max_value + 1;
             while (hi - lo > 1) {
                 const int32_t mid = (lo + hi) >> 1;
                 if ((uint32_t)row[mid] <= cf) lo = mid; else hi = mid;
@@ -229,19 +270,27 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
             s = lo;
         }
         const uint32_t start = (uint32_t)row[s], freq = (uint32_t)(row[s + 1] - row[s]);
-        d->x = (uint64_t)freq * (d->x >> kPrecision) + cf - start;
-        d->renorm();
+        x = (uint64_t)freq * (x >> kPrecision) + cf - start;
+        if (x < kRansL) {
+            const uint32_t w = pos < nw ? words[pos] : 0u;
+            ++pos;
+            x = (x << 32) | w;
+        }
         int32_t v = s;
-        if (v == max_value) {
+        if (__builtin_expect(v == max_value, 0)) {          // escape: Exp-Golomb-like nibbles through the bypass path
+            d->x = x; d->pos = pos;
             int32_t val = (int32_t)d->bits(), nb = val;
             while (val == kBypassMax) { val = (int32_t)d->bits(); nb += val; }
             uint32_t raw = 0;
             for (int32_t j = 0; j < nb && j < 8; ++j) raw |= d->bits() << (j * kBypassBits);
             v = (int32_t)(raw >> 1);
             v = (raw & 1u) ? -v - 1 : v + max_value;
+            x = d->x; pos = d->pos;
+            if (pos > nw + 2) { dsvc_set_error("rans_decode: stream exhausted at symbol %lld", (long long)i); return DSVC_E_RANGE; }
         }
         out[i] = v + t->offset[ci];
-        if (d->pos > d->words.size() + 2) { dsvc_set_error("rans_decode: stream exhausted at symbol %lld", (long long)i); return DSVC_E_RANGE; }
     }
+    d->x = x; d->pos = pos;
+    if (pos > nw + 2) { dsvc_set_error("rans_decode: stream exhausted within %lld symbols", (long long)n); return DSVC_E_RANGE; }
     return DSVC_OK;
 }
