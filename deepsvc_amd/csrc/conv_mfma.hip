@@ -267,6 +267,44 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                             }
                         }
             };
+            if constexpr (MT == 4) {
+                // 16-row tiles: 128+ accumulator registers leave no room for two whole taps of fragments; pipeline at the
+                // granularity of one 16-deep k-step (6-7 reads ahead of 8-12 MFMAs) instead
+                struct FragsK { uint4 a[MT], b[NT]; };
+                int rks = 0;
+                auto read_step = [&](FragsK& f) {
+                    const int tap_off = (ky * PWL + kx) * ROWB + rks * 16;
+                    const char* wt = lds_w + rt * NTN * ROWB + rks * 16;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) f.b[n] = *(const uint4*)(wt + b_off[n]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) f.a[m] = *(const uint4*)(lds_a + a_off[m] + tap_off);
+                    if (rks == 1 && rt + 1 < tcur) { ++rt; if (++kx == p.kw) { kx = 0; ++ky; } }
+                    rks ^= 1;
+                };
+                auto mfma_step = [&](const FragsK& f) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, f.a[m]), __builtin_bit_cast(bf16x8, f.b[n]), acc[m][n], 0, 0, 0);
+                };
+                FragsK gA, gB;
+                read_step(gA);
+                for (int i = 0; i < tcur; ++i) {
+                    read_step(gB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(gA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_step(gA);                     // past the last step: re-reads the last tap (branch-free)
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(gB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (++kx == p.kw) { kx = 0; ++ky; }
+                continue;
+            }
             Frags fA, fB;
             read_tap(fA);
             for (int i = 0; i < (tcur >> 1); ++i) {
@@ -289,25 +327,29 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     // Accumulators go through a wave-private LDS slab [pixel][channel] (<= 2 N-tiles per pass) so the fused
     // bias/activation/residual/store code is a short rolled loop moving 16-byte vectors along the NHWC channel axis.
     constexpr int EPN = NT >= 2 ? 2 : 1;
+    constexpr int EPM = MT >= 2 ? 2 : 1;            // output rows per pass (the slab of a 16-row tile would not leave room for a second workgroup)
     constexpr int EPC = EPN * 32, EPLD = EPC + 4, GPP = EPC / 4;
-    float* slab = (float*)smem + (size_t)wave * (MT * 32 * EPLD);
+    float* slab = (float*)smem + (size_t)wave * (EPM * 32 * EPLD);
     const EpiRsrc R = make_epi_rsrc(p);
 #pragma unroll
     for (int n0 = 0; n0 < NT; n0 += EPN) {
-        lds_barrier();
 #pragma unroll
-        for (int e = 0; e < EPN; ++e) {
-            if (n0 + e < NT) {
+        for (int m0 = 0; m0 < MT; m0 += EPM) {
+            lds_barrier();
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+            for (int e = 0; e < EPN; ++e) {
+                if (n0 + e < NT) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        slab[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[m][n0 + e < NT ? n0 + e : 0][i];
+                    for (int m = 0; m < EPM; ++m)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            slab[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[m0 + m][n0 + e < NT ? n0 + e : 0][i];
+                }
             }
+            lds_barrier();
+            const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
+            run_epilogue<GPP, EPLD, EPM * 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);
         }
-        lds_barrier();
-        const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
-        run_epilogue<GPP, EPLD, MT * 32>(p, R, slab, lane, b, oy0 + wave * MT, ox0, ng * NTN + n0 * 32, cpass);
     }
 }
 
@@ -338,6 +380,9 @@ int launch_nt(hipStream_t st, const ConvParams& p, int NT, int ngroups, size_t l
 
 template <typename CT>
 int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, int ngroups, size_t lds) {
+    if constexpr (sizeof(CT) == 2) {
+        if (MT == 4) return launch_cfg<CT, 4, 2, true>(st, p, ngroups, lds);      // 16x32-pixel tiles: bf16, vector staging, 64 output channels per group
+    }
     if (fast) return MT == 2 ? launch_nt<CT, 2, true>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, true>(st, p, NT, ngroups, lds);
     return MT == 2 ? launch_nt<CT, 2, false>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, false>(st, p, NT, ngroups, lds);
 }
@@ -481,6 +526,14 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     static const int mt_thr = getenv("DSVC_MT_THR") ? atoi(getenv("DSVC_MT_THR")) : 400;
     if (nblocks(MT, NT) < mt_thr && MT == 2) MT = 1;
     while (nblocks(MT, NT) < mt_thr && NT > 1) NT = (NT + 1) / 2;
+    // large bf16 stride-1 convs with 64 output channels per group: 16x32-pixel tiles -- 0.75 instead of 1.0 ds_read_b128 per
+    // MFMA and half the weight staging per pixel.  Worth only ~4 % (3x3 64+64->64 @1088x1920: 491 -> 471 us): the PMC
+    // counters put the LDS at ~35 % busy and the MFMA pipe at 36 %, i.e. the kernel waits on barriers and staging latency
+    // with two workgroups per CU, not on LDS bandwidth
+    if (MT == 2 && NT == 2 && fast && d->compute == DSVC_BF16 && d->stride == 1 && nblocks(4, NT) >= opt.tall_min_tiles) {
+        const size_t a4 = (size_t)(15 + d->kh) * (31 + d->kw) * ROWB;
+        if (a4 + (size_t)d->kw * NT * 32 * ROWB <= 78 * 1024) MT = 4;           // still two workgroups per CU
+    }
     const int TH = 4 * MT;
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
@@ -489,12 +542,12 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     const int PWL = d->stride == 2 ? 2 * ((PW + 1) / 2) : PW;      // LDS row pitch in pixels (stride 2: even | odd columns)
     const size_t lds_a = (size_t)PH * PWL * ROWB;
     const int ntaps = d->kh * d->kw;
-    const size_t budget = 78 * 1024;  // two workgroups per CU
+    const size_t budget = 78 * 1024;  // two workgroups per CU (one per CU: 96->96 154 -> 213 us, measured)
     p.tapg = ntaps;
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > budget) p.tapg = d->kw;
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > 160 * 1024) p.tapg = 1;
     const size_t lds_main = lds_a + (size_t)p.tapg * NT * 32 * ROWB;
-    const size_t lds_epi = (size_t)4 * MT * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
+    const size_t lds_epi = (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     DSVC_REQUIRE(lds <= 160 * 1024, "conv2d: LDS need %zu exceeds 160 KiB", lds);
 

@@ -273,6 +273,45 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
     report_close("direct vs torch", got, want, 2e-2 if out_dt == "bf16" else 5e-3, tol)
 
 
+@pytest.mark.parametrize("segs,cout,k,B,H,W,pre,act,res", [
+    ((64, 64), 64, 3, 1, 70, 100, 0, 2, False),          # two segments, ragged rows and columns (70 = 4*16 + 6)
+    ((32, 32), 64, 3, 2, 33, 45, 2, 2, True),            # batch 2, LeakyReLU in and out, bf16 residual
+    ((32,), 64, 5, 1, 50, 64, 0, 1, False),              # 5x5: tap groups of one kernel row
+    ((64, 8), 128, 3, 1, 48, 96, 0, 0, False),           # 128 output channels = two groups of 64
+])
+def test_conv_tall_tile_variant(segs, cout, k, B, H, W, pre, act, res):
+    """The generic kernel's 16x32-pixel tile variant (bf16, stride 1, 64 output channels per group; picked from
+    `tall_min_tiles` tiles on) against the 8x32 tiling of the same kernel -- identical accumulation order per output,
+    so bit-identical results -- and against torch on bf16-rounded operands."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + W)
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    was_s, was_t = ops.set_option("specialised", 0), ops.set_option("tall_min_tiles", 1)
+    try:
+        m = Conv2d(sum(segs), cout, k, 1, k // 2).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        ins = [_act(x, bf) for x in xs]
+        r = torch.randn(B, cout, H, W) if res else None
+        kw = dict(pre_act=pre, act=act, slope=0.05, out_dtype=torch.float32)
+        if res:
+            kw["res1"] = _act(r, bf)
+        tall = m.run(ins if len(ins) > 1 else ins[0], **kw).nchw().float().cpu()
+        ops.set_option("tall_min_tiles", 1 << 30)
+        flat = m.run(ins if len(ins) > 1 else ins[0], **kw).nchw().float().cpu()
+    finally:
+        ops.set_option("specialised", was_s); ops.set_option("tall_min_tiles", was_t)
+        ops.set_precision("fp32")
+    assert torch.equal(tall, flat), f"16-row and 8-row tilings differ: max |d| = {float((tall - flat).abs().max()):.3e}"
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    xb = torch.cat([_torch_act(x.to(bf).float(), pre, 0.05).to(bf).float() for x in xs], 1)
+    want = _torch_act(F.conv2d(xb, w, b, padding=k // 2), act, 0.05)
+    if res:
+        want = want + r.to(bf).float()
+    report_close("tall tile vs torch", tall, want, 5e-3, 5e-3 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,pre,act", [
     ((96, 48), ("f32", "f32"), 96, 1, 68, 120, 0, 3),                 # cc_mean/cc_scale first layer
     ((96, 36), ("f32", "f32"), 96, 1, 68, 120, 0, 3),                 # 36 = 32 + a half-filled quarter (C % 8 == 4)
