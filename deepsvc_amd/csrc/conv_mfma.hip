@@ -271,16 +271,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                 // 16-row tiles: 128+ accumulator registers leave no room for two whole taps of fragments; pipeline at the
                 // granularity of one 16-deep k-step (6-7 reads ahead of 8-12 MFMAs) instead
                 struct FragsK { uint4 a[MT], b[NT]; };
-                int rks = 0;
-                auto read_step = [&](FragsK& f) {
-                    const int tap_off = (ky * PWL + kx) * ROWB + rks * 16;
-                    const char* wt = lds_w + rt * NTN * ROWB + rks * 16;
+                auto read_step = [&](FragsK& f, int ks) {          // ks is a literal at every call site: straight-line code
+                    const int tap_off = (ky * PWL + kx) * ROWB + ks * 16;
+                    const char* wt = lds_w + rt * NTN * ROWB + ks * 16;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) f.b[n] = *(const uint4*)(wt + b_off[n]);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) f.a[m] = *(const uint4*)(lds_a + a_off[m] + tap_off);
-                    if (rks == 1 && rt + 1 < tcur) { ++rt; if (++kx == p.kw) { kx = 0; ++ky; } }
-                    rks ^= 1;
                 };
                 auto mfma_step = [&](const FragsK& f) {
 #pragma unroll
@@ -290,16 +287,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 __builtin_bit_cast(bf16x8, f.a[m]), __builtin_bit_cast(bf16x8, f.b[n]), acc[m][n], 0, 0, 0);
                 };
-                FragsK gA, gB;
-                read_step(gA);
+                FragsK g0, g1;
+                read_step(g0, 0);
                 for (int i = 0; i < tcur; ++i) {
-                    read_step(gB);
+                    read_step(g1, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_step(gA);
+                    mfma_step(g0);
                     __builtin_amdgcn_sched_barrier(0);
-                    read_step(gA);                     // past the last step: re-reads the last tap (branch-free)
+                    if (rt + 1 < tcur) { ++rt; if (++kx == p.kw) { kx = 0; ++ky; } }
+                    read_step(g0, 0);                  // past the last tap: re-reads it (branch-free loop body)
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_step(gB);
+                    mfma_step(g1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (++kx == p.kw) { kx = 0; ++ky; }
@@ -341,14 +339,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                 if (n0 + e < NT) {
 #pragma unroll
                     for (int m = 0; m < EPM; ++m)
+                        if (m0 + m < MT) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            slab[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[m0 + m][n0 + e < NT ? n0 + e : 0][i];
+                            for (int i = 0; i < 16; ++i)
+                                slab[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[m0 + m < MT ? m0 + m : 0][n0 + e < NT ? n0 + e : 0][i];
+                        }
                 }
             }
             lds_barrier();
             const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
-            run_epilogue<GPP, EPLD, EPM * 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);
+            if (m0 + EPM <= MT) run_epilogue<GPP, EPLD, EPM * 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);
+            else run_epilogue<GPP, EPLD, 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);     // odd last row
         }
     }
 }
@@ -530,6 +531,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     // MFMA and half the weight staging per pixel.  Worth only ~4 % (3x3 64+64->64 @1088x1920: 491 -> 471 us): the PMC
     // counters put the LDS at ~35 % busy and the MFMA pipe at 36 %, i.e. the kernel waits on barriers and staging latency
     // with two workgroups per CU, not on LDS bandwidth
+    // (96 output channels: 16 rows spill -- 192 accumulator registers --, and a 12-row variant measured 237 vs 152 us)
     if (MT == 2 && NT == 2 && fast && d->compute == DSVC_BF16 && d->stride == 1 && nblocks(4, NT) >= opt.tall_min_tiles) {
         const size_t a4 = (size_t)(15 + d->kh) * (31 + d->kw) * ROWB;
         if (a4 + (size_t)d->kw * NT * 32 * ROWB <= 78 * 1024) MT = 4;           // still two workgroups per CU

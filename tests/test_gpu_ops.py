@@ -278,6 +278,7 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
     ((32, 32), 64, 3, 2, 33, 45, 2, 2, True),            # batch 2, LeakyReLU in and out, bf16 residual
     ((32,), 64, 5, 1, 50, 64, 0, 1, False),              # 5x5: tap groups of one kernel row
     ((64, 8), 128, 3, 1, 48, 96, 0, 0, False),           # 128 output channels = two groups of 64
+    ((64, 32), 64, 3, 2, 25, 33, 1, 0, False),           # three chunks over two segments, batch 2, ReLU on the way in
 ])
 def test_conv_tall_tile_variant(segs, cout, k, B, H, W, pre, act, res):
     """The generic kernel's 16x32-pixel tile variant (bf16, stride 1, 64 output channels per group; picked from

@@ -39,6 +39,11 @@ SHAPES = [  # (name, segs, cout, k, stride, H, W, kwargs)
     ("1x1 64->32 @1/1 gate+res", (64,), 32, 1, 1, 1088, 1920, {"res": True, "gate": True}),
     ("1x1 64+64->64 @1/2 gate+res", (64, 64), 64, 1, 1, 544, 960, {"res": True, "gate": True}),
 ]
+SHAPES += [
+    ("3x3 32+32->64 @1/1 lrelu", (32, 32), 64, 3, 1, 1088, 1920, {"act": True}),
+    ("3x3 64+32->64 @1/1", (64, 32), 64, 3, 1, 1088, 1920, {}),
+    ("3x3 64+8->64 @1/1", (64, 8), 64, 3, 1, 1088, 1920, {}),
+]
 
 
 def main():
@@ -59,7 +64,7 @@ def main():
         Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
         out = ops.new_act(1, Ho, Wo, cout, st, dev)
         res = ops.Act(torch.randn((1, Ho, Wo, cout), device=dev).to(st)) if kw.get("res") else None
-        ep = dict(res1=res, pre_act=N.ACT_LRELU if kw.get("pre") else N.ACT_NONE, act=N.ACT_LRELU if kw.get("pre") else N.ACT_NONE)
+        ep = dict(res1=res, pre_act=N.ACT_LRELU if kw.get("pre") else N.ACT_NONE, act=N.ACT_LRELU if (kw.get("pre") or kw.get("act")) else N.ACT_NONE)
         if kw.get("gate"):
             ep["gate"] = torch.rand((1, cout), device=dev)
         for _ in range(3):
