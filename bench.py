@@ -214,8 +214,14 @@ def main():
                     "kernel": "3x3 s1 64->64 conv @%dx%d (bf16: conv3x3_pp_kernel, fp32: conv_mfma_kernel)" % (H_pad, W_pad),
                     "launches": len(durs), "avg_ms": avg_ms, "isolated_avg_ms": iso_ms,
                     "isolated_achieved": conv_flop / (iso_ms * 1e-3) / 1e12 if iso_ms else None,
-                    "note": "avg_ms: HIP events around every launch of this shape inside the timed region (with >1 GOP lane it "
-                            "includes time-sharing with the other lanes' kernels); isolated_*: the same launch on an idle GPU"}
+                    "isolated_frac": conv_flop / (iso_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision] if iso_ms else None,
+                    "isolated_hbm_frac": (2.0 * H_pad * W_pad * 64 * (2 if args.precision == "bf16" else 4) / (iso_ms * 1e-3) / 8e12) if iso_ms else None,
+                    "concurrent_lanes": args.lanes,
+                    "note": "achieved/frac/avg_ms: HIP events around every launch of this shape inside the timed region -- with "
+                            "concurrent_lanes > 1 the launch shares the GPU with the other lanes' kernels, so its duration (and the "
+                            "rocprofv3 per-kernel average of the same command) is ~lanes x the kernel's own time; isolated_*: the same "
+                            "launch on an idle GPU after the timed region = what `--lanes 1` and its rocprofv3 summary show "
+                            "(arithmetic intensity 288 FLOP/B sits at the machine balance 2500/8 = 312, hence both fractions)"}
         summ = harness.summarise(table)
         line = {
             "metric": "encode+decode fps @1080p", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
