@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdsvc.so")
+LIB_PATH = os.environ.get("DSVC_LIB") or os.path.join(HERE, "lib", "libdsvc.so")     # DSVC_LIB: an instrumented build (tools/phase_probe.py)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_HALF_TANH = range(6)

@@ -28,6 +28,23 @@ int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_direct_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
+#ifdef DSVC_PHASE_PROBE
+// Build with DSVC_BUILD_DEFINES=-DDSVC_PHASE_PROBE (deepsvc_amd/build.py) to get per-phase shader-clock totals of wave 0 of
+// every workgroup of conv_mfma_kernel (tools/phase_probe.py reads them): [0] barrier before staging, [1] patch staging,
+// [2] weight staging, [3] barrier before the MFMAs, [4] MFMA phase, [5] epilogue, [6] whole kernel, [7] workgroups.
+__device__ unsigned long long g_phase[8];
+#define PROBE_STAMP(var) unsigned long long var = 0; if (probe) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define PROBE_ADD(i, a, b) if (probe) ph[i] += (b) - (a);
+extern "C" int dsvc_dbg_phase_read(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define PROBE_STAMP(var)
+#define PROBE_ADD(i, a, b)
+#endif
+
 namespace {
 using namespace dsvc_conv;
 
@@ -83,7 +100,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) b_off[n] = (n * 32 + r) * ROWB + h * 32;
 
+#ifdef DSVC_PHASE_PROBE
+    const bool probe = tid == 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    PROBE_STAMP(t_begin)
     for (int ch = 0; ch < p.nchunks; ++ch) {
+        PROBE_STAMP(t_a)
         int s = 0;
         if (p.nseg > 1 && ch >= p.seg[1].chunk0) s = 1;
         if (p.nseg > 2 && ch >= p.seg[2].chunk0) s = 2;
@@ -91,6 +114,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         const int c0 = (ch - sg.chunk0) * KCE;
 
         lds_barrier();  // all waves done with the previous chunk's LDS contents (LDS-only: global traffic stays in flight)
+        PROBE_STAMP(t_b)
+        PROBE_ADD(0, t_a, t_b)
         // ---- stage the input halo patch of this channel chunk ----
         // Loads of a batch are all issued before the first LDS store so their L2/HBM latencies overlap.
         bool staged = false;
@@ -158,7 +183,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     const int iy = iy0 + py, ix = ix0 + px;
                     lr[j] = lds_row(py, px);
                     const bool inb = qvalid && base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    v[j] = buf_load16(rs, inb ? img + ((unsigned)iy * rowstep + (unsigned)ix * pixstep) * pitch : OOB);
+                    // (offset | OOB, not a select of offsets: hipcc turns the select into exec-mask branches and then waits for
+                    //  ALL outstanding loads at every merge point, which serialises the batch)
+                    v[j] = buf_load16(rs, (img + ((unsigned)iy * rowstep + (unsigned)ix * pixstep) * pitch) | (inb ? 0u : OOB));
                     px += dpx; py += dpy;
                     if (px >= PW) { px -= PW; ++py; }
                 }
@@ -205,14 +232,23 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             }
         }
 
+        PROBE_STAMP(t_c)
+        PROBE_ADD(1, t_b, t_c)
         int ky = 0, kx = 0;
         for (int tg0 = 0; tg0 < ntaps; tg0 += p.tapg) {
             const int tcur = min(p.tapg, ntaps - tg0);
+            PROBE_STAMP(t_d0)
             if (tg0 > 0) lds_barrier();
+            PROBE_STAMP(t_d)
+            PROBE_ADD(0, t_d0, t_d)
             // ---- stage the weights of taps [tg0, tg0+tcur) for this chunk and N group (batched loads) ----
             {
+                // bounds-checked buffer loads, masked by the offset: a conditional global load per vector made hipcc wait for every
+                // load before issuing the next (s_waitcnt vmcnt(0) at each merge) -- nine serial L2 round trips per staging step,
+                // 30 % of a workgroup's time (tools/phase_probe.py)
                 constexpr int WB = 9;
-                const char* wbase = (const char*)p.w + (size_t)b * p.w_bs + (((size_t)ch * ntaps + tg0) * p.Np + (size_t)ng * NTN) * 64 + q * 16;
+                const rsrc_t rw = make_rsrc((const char*)p.w + (size_t)b * p.w_bs, p.w_bytes);
+                const unsigned wbase = (((unsigned)ch * ntaps + tg0) * p.Np + (unsigned)ng * NTN) * 64u + q * 16u;
                 const bool wfull = (ng + 1) * NTN <= p.Np;
                 const int nrows = tcur * NTN;
                 for (int base = tid >> 2; base < nrows; base += 64 * WB) {
@@ -221,15 +257,19 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     for (int j = 0; j < WB; ++j) {
                         const int row = base + 64 * j;
                         const int t = row / NTN, n = row - t * NTN;
-                        v[j] = make_uint4(0, 0, 0, 0);
-                        if (row < nrows && (wfull || ng * NTN + n < p.Np)) v[j] = *(const uint4*)(wbase + ((size_t)t * p.Np + n) * 64);
+                        const bool ok = row < nrows && (wfull || ng * NTN + n < p.Np);
+                        v[j] = buf_load16(rw, (wbase + ((unsigned)t * p.Np + (unsigned)n) * 64u) | (ok ? 0u : OOB));
                     }
 #pragma unroll
                     for (int j = 0; j < WB; ++j)
                         if (base + 64 * j < nrows) *(uint4*)(lds_w + (base + 64 * j) * ROWB + q * 16) = v[j];
                 }
             }
+            PROBE_STAMP(t_e)
+            PROBE_ADD(2, t_d, t_e)
             lds_barrier();
+            PROBE_STAMP(t_f)
+            PROBE_ADD(3, t_e, t_f)
 
             // ---- MFMA phase, software-pipelined over taps: while the MFMAs of one tap run, the LDS reads of the next
             // tap are already in flight.  Two named fragment sets (static register indexing), branch-free loop body
@@ -301,6 +341,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (++kx == p.kw) { kx = 0; ++ky; }
+                PROBE_STAMP(t_g4)
+                PROBE_ADD(4, t_f, t_g4)
                 continue;
             }
             Frags fA, fB;
@@ -317,8 +359,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             }
             if (tcur & 1) mfma_tap(fA);
             if (++kx == p.kw) { kx = 0; ++ky; }            // step past the group's last tap for the next group
+            PROBE_STAMP(t_g)
+            PROBE_ADD(4, t_f, t_g)
         }
     }
+    PROBE_STAMP(t_epi)
 
     // ---- epilogue ----
     // MFMA C/D layout: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel).
@@ -352,6 +397,15 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             else run_epilogue<GPP, EPLD, 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);     // odd last row
         }
     }
+#ifdef DSVC_PHASE_PROBE
+    PROBE_STAMP(t_end)
+    if (probe) {
+        ph[5] += t_end - t_epi;
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_phase[i], ph[i]);
+        atomicAdd(&g_phase[6], t_end - t_begin);
+        atomicAdd(&g_phase[7], 1ull);
+    }
+#endif
 }
 
 template <typename CT, int MT, int NT, bool FAST>
@@ -458,6 +512,11 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     DSVC_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d: empty output");
     p.Cout = d->Cout; p.Np = (d->Cout + 31) / 32 * 32;
     p.w = d->weight; p.bias = d->bias;
+    {
+        const int64_t wb = (int64_t)chunk0 * d->kh * d->kw * p.Np * 64;       // packed weights of one conv (dsvc_conv_packed_bytes)
+        DSVC_REQUIRE(wb < 0x7FFFFFF0ll, "conv2d: packed weights of %lld bytes exceed 2 GiB", (long long)wb);
+        p.w_bytes = (unsigned)wb;
+    }
     p.pre_act = d->pre_act; p.act = d->act; p.slope = d->slope;
     p.res1 = d->res1; p.res1_ld = d->res1_ld; p.res1_dtype = d->res1_dtype; p.res1_scale = d->res1_scale;
     p.res2 = d->res2; p.res2_ld = d->res2_ld; p.res2_dtype = d->res2_dtype;
