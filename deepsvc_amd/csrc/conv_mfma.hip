@@ -100,6 +100,27 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) b_off[n] = (n * 32 + r) * ROWB + h * 32;
 
+    // ---- weight prefetch: the packed weights of the NEXT staging step travel L2 -> registers while the MFMAs of the
+    // current one run (a staging step is one L2 round trip of ~2.5 k clocks with nothing else to do in this workgroup:
+    // 30 % of its time, tools/phase_probe.py).  WP = vectors per thread that fit the register budget of the variant.
+    constexpr int WP = (MT == 4 || sizeof(CT) == 4) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 0);
+    uint4 wv[WP > 0 ? WP : 1];
+    const rsrc_t rw = make_rsrc((const char*)p.w + (size_t)b * p.w_bs, p.w_bytes);
+    const bool wfull = (ng + 1) * NTN <= p.Np;
+    auto w_issue = [&](int ch2, int tg2, bool any) {       // any = false: past the last step, every lane masked (no branch: a
+        if constexpr (WP > 0) {                            // conditional call would be a merge point, where hipcc drains vmcnt)
+            const unsigned wbase = (((unsigned)ch2 * ntaps + tg2) * p.Np + (unsigned)ng * NTN) * 64u + q * 16u;
+            const int nrows = min(p.tapg, ntaps - tg2) * NTN;
+#pragma unroll
+            for (int j = 0; j < WP; ++j) {
+                const int row = (tid >> 2) + 64 * j;
+                const int t = row / NTN, n = row - t * NTN;
+                const bool ok = any && row < nrows && (wfull || ng * NTN + n < p.Np);
+                wv[j] = buf_load16(rw, (wbase + ((unsigned)t * p.Np + (unsigned)n) * 64u) | (ok ? 0u : OOB));
+            }
+        }
+    };
+    w_issue(0, 0, true);
 #ifdef DSVC_PHASE_PROBE
     const bool probe = tid == 0;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
@@ -242,14 +263,23 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             PROBE_STAMP(t_d)
             PROBE_ADD(0, t_d0, t_d)
             // ---- stage the weights of taps [tg0, tg0+tcur) for this chunk and N group (batched loads) ----
-            {
+            if constexpr (WP > 0) {          // (compile-time choice: a run-time one merges two paths and hipcc then drains vmcnt at the join)
+                {
+                    const int nrows = tcur * NTN;
+#pragma unroll
+                    for (int j = 0; j < WP; ++j) {
+                        const int row = (tid >> 2) + 64 * j;
+                        if (row < nrows) *(uint4*)(lds_w + row * ROWB + q * 16) = wv[j];
+                    }
+                    const bool more_tg = tg0 + p.tapg < ntaps;
+                    w_issue(more_tg ? ch : ch + 1, more_tg ? tg0 + p.tapg : 0, more_tg || ch + 1 < p.nchunks);
+                }
+            } else {
                 // bounds-checked buffer loads, masked by the offset: a conditional global load per vector made hipcc wait for every
                 // load before issuing the next (s_waitcnt vmcnt(0) at each merge) -- nine serial L2 round trips per staging step,
                 // 30 % of a workgroup's time (tools/phase_probe.py)
                 constexpr int WB = 9;
-                const rsrc_t rw = make_rsrc((const char*)p.w + (size_t)b * p.w_bs, p.w_bytes);
                 const unsigned wbase = (((unsigned)ch * ntaps + tg0) * p.Np + (unsigned)ng * NTN) * 64u + q * 16u;
-                const bool wfull = (ng + 1) * NTN <= p.Np;
                 const int nrows = tcur * NTN;
                 for (int base = tid >> 2; base < nrows; base += 64 * WB) {
                     uint4 v[WB];
@@ -607,7 +637,12 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     p.tapg = ntaps;
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > budget) p.tapg = d->kw;
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > 160 * 1024) p.tapg = 1;
+    {   // the weight prefetch registers of the kernel variant (WP in conv_mfma_kernel) hold one whole staging step
+        const int wp = (MT == 4 || d->compute != DSVC_BF16) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 0);
+        if (wp > 0 && (p.tapg * NT + 1) / 2 > wp) p.tapg = 2 * wp / NT;
+    }
     const size_t lds_main = lds_a + (size_t)p.tapg * NT * 32 * ROWB;
+
     const size_t lds_epi = (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     DSVC_REQUIRE(lds <= 160 * 1024, "conv2d: LDS need %zu exceeds 160 KiB", lds);
