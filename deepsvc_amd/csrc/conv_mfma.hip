@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     // ---- weight prefetch: the packed weights of the NEXT staging step travel L2 -> registers while the MFMAs of the
     // current one run (a staging step is one L2 round trip of ~2.5 k clocks with nothing else to do in this workgroup:
     // 30 % of its time, tools/phase_probe.py).  WP = vectors per thread that fit the register budget of the variant.
-    constexpr int WP = (MT == 4 || sizeof(CT) == 4) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 0);
+    constexpr int WP = (MT == 4 || sizeof(CT) == 4) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
     uint4 wv[WP > 0 ? WP : 1];
     const rsrc_t rw = make_rsrc((const char*)p.w + (size_t)b * p.w_bs, p.w_bytes);
     const bool wfull = (ng + 1) * NTN <= p.Np;
@@ -337,12 +337,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                             }
                         }
             };
-            if constexpr (MT == 4) {
-                // 16-row tiles: 128+ accumulator registers leave no room for two whole taps of fragments; pipeline at the
+            if constexpr (MT == 4 || (NT == 4 && sizeof(CT) == 2)) {
+                // 16-row tiles (and 128-channel groups, to make room for the weight prefetch): 128+ accumulator registers leave no room for two whole taps of fragments; pipeline at the
                 // granularity of one 16-deep k-step (6-7 reads ahead of 8-12 MFMAs) instead
                 struct FragsK { uint4 a[MT], b[NT]; };
                 auto read_step = [&](FragsK& f, int ks) {          // ks is a literal at every call site: straight-line code
-                    const int tap_off = (ky * PWL + kx) * ROWB + ks * 16;
+                    const int tap_off = (ky * PWL + (s2 ? (kx & 1) * PWh + (kx >> 1) : kx)) * ROWB + ks * 16;
                     const char* wt = lds_w + rt * NTN * ROWB + ks * 16;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) f.b[n] = *(const uint4*)(wt + b_off[n]);
@@ -638,7 +638,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > budget) p.tapg = d->kw;
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > 160 * 1024) p.tapg = 1;
     {   // the weight prefetch registers of the kernel variant (WP in conv_mfma_kernel) hold one whole staging step
-        const int wp = (MT == 4 || d->compute != DSVC_BF16) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 0);
+        const int wp = (MT == 4 || d->compute != DSVC_BF16) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
         if (wp > 0 && (p.tapg * NT + 1) / 2 > wp) p.tapg = 2 * wp / NT;
     }
     const size_t lds_main = lds_a + (size_t)p.tapg * NT * 32 * ROWB;

@@ -273,6 +273,39 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
     report_close("direct vs torch", got, want, 2e-2 if out_dt == "bf16" else 5e-3, tol)
 
 
+@pytest.mark.parametrize("segs,cout,k,stride,H,W,act,res", [
+    ((128,), 128, 3, 1, 160, 320, 1, True),        # UNet bottleneck ResBlock shape class: four N-tiles per workgroup
+    ((96,), 128, 5, 2, 512, 512, 0, False),        # stride 2 (even/odd column LDS layout) with four N-tiles
+    ((64,), 256, 3, 1, 160, 320, 3, False),        # two groups of four N-tiles
+    ((96,), 96, 3, 1, 200, 320, 2, True),          # three N-tiles, tap groups of one kernel row, weight prefetch across groups
+])
+def test_conv_wide_output_variants(segs, cout, k, stride, H, W, act, res):
+    """Images large enough that the generic kernel keeps 3-4 N-tiles (96-128 output channels) per workgroup: the variants
+    with register-prefetched weights and (for 128 channels) k-step fragment pipelining -- against torch on bf16-rounded operands."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + W)
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    try:
+        m = Conv2d(sum(segs), cout, k, stride, k // 2).to(DEV)
+        xs = [torch.randn(1, c, H, W) for c in segs]
+        ins = [_act(x, bf) for x in xs]
+        Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+        r = torch.randn(1, cout, Ho, Wo) if res else None
+        kw = dict(act=act, slope=0.05, out_dtype=torch.float32)
+        if res:
+            kw["res1"] = _act(r, bf)
+        got = m.run(ins[0], **kw).nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    want = _torch_act(F.conv2d(xs[0].to(bf).float(), w, b, stride=stride, padding=k // 2), act, 0.05)
+    if res:
+        want = want + r.to(bf).float()
+    report_close("wide conv vs torch", got, want, 5e-3, 5e-3 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("segs,cout,k,B,H,W,pre,act,res", [
     ((64, 64), 64, 3, 1, 70, 100, 0, 2, False),          # two segments, ragged rows and columns (70 = 4*16 + 6)
     ((32, 32), 64, 3, 2, 33, 45, 2, 2, True),            # batch 2, LeakyReLU in and out, bf16 residual
