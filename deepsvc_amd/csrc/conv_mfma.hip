@@ -48,7 +48,12 @@ extern "C" int dsvc_dbg_phase_read(unsigned long long* out8, int reset) {
 namespace {
 using namespace dsvc_conv;
 
-template <typename CT, int MT, int NT, bool FAST>
+// REGEPI: the MFMA operands are swapped (A = weights, B = pixels), so a lane ends up with 16 output channels of ONE pixel
+// and the epilogue needs no LDS: one 32-lane swap turns them into two runs of 8 consecutive channels = two 16-byte bf16
+// stores (the slab epilogue -- accumulators through LDS, two extra barriers per pass -- is ~20 % of a workgroup's time on
+// the large convs, tools/phase_probe.py).  Taken for bf16 output, whole 32-channel tiles, act in {none, relu, lrelu},
+// at most one bf16 residual; everything else keeps the slab epilogue.
+template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KCE = CTraits<CT>::KCE, EPV = CTraits<CT>::EPV;
@@ -333,7 +338,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[m][n], 0, 0, 0);
                             } else {
                                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(bf16x8, f.a[ks][m]), __builtin_bit_cast(bf16x8, f.b[ks][n]), acc[m][n], 0, 0, 0);
+                                    __builtin_bit_cast(bf16x8, REGEPI ? f.b[ks][n] : f.a[ks][m]),
+                                    __builtin_bit_cast(bf16x8, REGEPI ? f.a[ks][m] : f.b[ks][n]), acc[m][n], 0, 0, 0);
                             }
                         }
             };
@@ -355,7 +361,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, f.a[m]), __builtin_bit_cast(bf16x8, f.b[n]), acc[m][n], 0, 0, 0);
+                                __builtin_bit_cast(bf16x8, REGEPI ? f.b[n] : f.a[m]), __builtin_bit_cast(bf16x8, REGEPI ? f.a[m] : f.b[n]), acc[m][n], 0, 0, 0);
                 };
                 FragsK g0, g1;
                 read_step(g0, 0);
@@ -399,6 +405,65 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     // MFMA C/D layout: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel).
     // Accumulators go through a wave-private LDS slab [pixel][channel] (<= 2 N-tiles per pass) so the fused
     // bias/activation/residual/store code is a short rolled loop moving 16-byte vectors along the NHWC channel axis.
+    if constexpr (REGEPI) {
+        // D[channel][pixel]: lane (r, h) holds pixel ox0 + r, channels (i & 3) + 8 * (i >> 2) + 4 * h of every 32-channel tile
+        const EpiRsrc R = make_epi_rsrc(p);
+        const rsrc_t rbias = make_rsrc(p.bias ? (const void*)(p.bias + (size_t)b * p.bias_bs) : (const void*)p.out, p.bias ? (unsigned)p.Cout * 4u : 0u);
+        const float sl = p.act == DSVC_ACT_NONE ? 1.f : (p.act == DSVC_ACT_RELU ? 0.f : p.slope);      // act(v) = max(v, v * sl)
+        const unsigned r1m = p.res1 ? 0u : OOB;
+        const int ox = ox0 + r;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ct = ng * NTN + n * 32;                       // first channel of this tile (uniform)
+            const unsigned cm = ct < p.Cout ? 0u : OOB;
+            const unsigned co0 = (unsigned)(ct + 8 * h);            // after the swap: channels co0..co0+7 and co0+16..co0+23
+            const uint4 ba = buf_load16(rbias, (co0 * 4u) | cm), bb = buf_load16(rbias, (co0 * 4u + 16u) | cm);
+            const uint4 bc = buf_load16(rbias, (co0 * 4u + 64u) | cm), bd = buf_load16(rbias, (co0 * 4u + 80u) | cm);
+            const unsigned bw0[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w}, bw1[8] = {bc.x, bc.y, bc.z, bc.w, bd.x, bd.y, bd.z, bd.w};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int oy = oy0 + wave * MT + m;
+                const unsigned pm = (oy < p.Ho && ox < p.Wo) ? cm : OOB;
+                const unsigned opix = ((unsigned)b * p.Ho + (unsigned)oy) * p.Wo + (unsigned)ox;
+                const uint4 ra = buf_load16(R.r1, ((opix * p.res1_ld + co0) * 2u) | pm | r1m);
+                const uint4 rb = buf_load16(R.r1, ((opix * p.res1_ld + co0) * 2u + 32u) | pm | r1m);
+                float v0[8], v1[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    {   // scalars first: hipcc 7.2 mis-casts vector elements
+                        const float xq = acc[m][n][j], yq = acc[m][n][4 + j];
+                        const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false);
+                        const unsigned lo_ = sw.x, hi_ = sw.y;
+                        v0[j] = __builtin_bit_cast(float, lo_); v0[4 + j] = __builtin_bit_cast(float, hi_);
+                    }
+                    {
+                        const float xq = acc[m][n][8 + j], yq = acc[m][n][12 + j];
+                        const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false);
+                        const unsigned lo_ = sw.x, hi_ = sw.y;
+                        v1[j] = __builtin_bit_cast(float, lo_); v1[4 + j] = __builtin_bit_cast(float, hi_);
+                    }
+                }
+                const unsigned ru0[4] = {ra.x, ra.y, ra.z, ra.w}, ru1[4] = {rb.x, rb.y, rb.z, rb.w};
+                unsigned o0[4], o1[4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t0 = v0[j] + __builtin_bit_cast(float, bw0[j]), t1 = v1[j] + __builtin_bit_cast(float, bw1[j]);
+                    v0[j] = fmaxf(t0, t0 * sl); v1[j] = fmaxf(t1, t1 * sl);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v0[2 * j] += __builtin_bit_cast(float, ru0[j] << 16); v0[2 * j + 1] += __builtin_bit_cast(float, ru0[j] & 0xFFFF0000u);
+                    v1[2 * j] += __builtin_bit_cast(float, ru1[j] << 16); v1[2 * j + 1] += __builtin_bit_cast(float, ru1[j] & 0xFFFF0000u);
+                    o0[j] = (unsigned)f32_to_bf16_bits(v0[2 * j]) | ((unsigned)f32_to_bf16_bits(v0[2 * j + 1]) << 16);
+                    o1[j] = (unsigned)f32_to_bf16_bits(v1[2 * j]) | ((unsigned)f32_to_bf16_bits(v1[2 * j + 1]) << 16);
+                }
+                const v4u_t s0 = {o0[0], o0[1], o0[2], o0[3]}, s1 = {o1[0], o1[1], o1[2], o1[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(s0, R.out, ((opix * p.out_ld + co0) * 2u) | pm, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(s1, R.out, ((opix * p.out_ld + co0) * 2u + 32u) | pm, 0, 0);
+            }
+        }
+        return;
+    }
     constexpr int EPN = NT >= 2 ? 2 : 1;
     constexpr int EPM = MT >= 2 ? 2 : 1;            // output rows per pass (the slab of a 16-row tile would not leave room for a second workgroup)
     constexpr int EPC = EPN * 32, EPLD = EPC + 4, GPP = EPC / 4;
@@ -438,10 +503,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
 #endif
 }
 
-template <typename CT, int MT, int NT, bool FAST>
+template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false>
 int launch_cfg(hipStream_t st, const ConvParams& p, int ngroups, size_t lds) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<CT, MT, NT, FAST>;
+    auto kern = conv_mfma_kernel<CT, MT, NT, FAST, REGEPI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
@@ -466,6 +531,12 @@ int launch_nt(hipStream_t st, const ConvParams& p, int NT, int ngroups, size_t l
 template <typename CT>
 int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, int ngroups, size_t lds) {
     if constexpr (sizeof(CT) == 2) {
+        if (p.regepi) {                       // register epilogue (see conv_mfma_kernel): large bf16 convs only
+            if (MT == 4) return launch_cfg<CT, 4, 2, true, true>(st, p, ngroups, lds);
+            if (NT == 2) return launch_cfg<CT, 2, 2, true, true>(st, p, ngroups, lds);
+            if (NT == 3) return launch_cfg<CT, 2, 3, true, true>(st, p, ngroups, lds);
+            return launch_cfg<CT, 2, 4, true, true>(st, p, ngroups, lds);
+        }
         if (MT == 4) return launch_cfg<CT, 4, 2, true>(st, p, ngroups, lds);      // 16x32-pixel tiles: bf16, vector staging, 64 output channels per group
     }
     if (fast) return MT == 2 ? launch_nt<CT, 2, true>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, true>(st, p, NT, ngroups, lds);
@@ -643,7 +714,14 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     }
     const size_t lds_main = lds_a + (size_t)p.tapg * NT * 32 * ROWB;
 
-    const size_t lds_epi = (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
+    {
+        auto al16 = [](const void* q, int ld) { return ((uintptr_t)q & 15) == 0 && (ld % 8) == 0; };
+        p.regepi = opt.reg_epilogue && fast && d->compute == DSVC_BF16 && (MT == 4 || (MT == 2 && NT >= 2)) && d->out_dtype == DSVC_BF16 &&
+                   d->shuffle == 1 && (d->Cout % 32) == 0 && al16(d->out, d->out_ld) && !d->res2 && !d->res1_scale &&
+                   (!d->res1 || (d->res1_dtype == DSVC_BF16 && al16(d->res1, d->res1_ld))) &&
+                   (d->act == DSVC_ACT_NONE || d->act == DSVC_ACT_RELU || (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f));
+    }
+    const size_t lds_epi = p.regepi ? 0 : (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     DSVC_REQUIRE(lds <= 160 * 1024, "conv2d: LDS need %zu exceeds 160 KiB", lds);
 

@@ -273,6 +273,51 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
     report_close("direct vs torch", got, want, 2e-2 if out_dt == "bf16" else 5e-3, tol)
 
 
+@pytest.mark.parametrize("segs,cout,k,stride,B,H,W,pre,act,res", [
+    ((96,), 96, 3, 1, 1, 200, 330, 0, 2, True),          # three N-tiles, LeakyReLU, bf16 residual, ragged right edge (330 = 10*32 + 10)
+    ((64, 64), 64, 3, 1, 2, 100, 200, 0, 0, False),      # two segments, batch 2, no activation
+    ((128,), 128, 3, 1, 1, 162, 320, 1, 1, True),        # four N-tiles (k-step pipeline), ReLU in and out, ragged bottom edge
+    ((32,), 64, 7, 1, 1, 120, 250, 0, 1, False),         # 7x7: tap groups of one kernel row
+    ((96,), 64, 5, 2, 1, 400, 512, 0, 0, False),         # stride 2
+    ((64,), 256, 3, 1, 1, 160, 320, 0, 2, False),        # two groups of four N-tiles
+])
+def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, H, W, pre, act, res):
+    """The generic kernel's LDS-free epilogue (MFMA operands swapped, one 32-lane swap, two 16-byte stores per lane and
+    32-channel tile) against the slab epilogue of the same kernel: same accumulation order, same arithmetic -> equal results;
+    and against torch on bf16-rounded operands."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + W)
+    bf = torch.bfloat16
+    ops.set_precision("bf16")
+    was_s, was_t = ops.set_option("specialised", 0), ops.set_option("tall_min_tiles", 1 if sum(segs) == 128 and cout == 64 else 1 << 30)
+    try:
+        m = Conv2d(sum(segs), cout, k, stride, k // 2).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        ins = [_act(x, bf) for x in xs]
+        Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+        r = torch.randn(B, cout, Ho, Wo) if res else None
+        kw = dict(pre_act=pre, act=act, slope=0.05, out_dtype=bf)
+        if res:
+            kw["res1"] = _act(r, bf)
+        inp = ins if len(ins) > 1 else ins[0]
+        ops.set_option("reg_epilogue", 1)
+        reg = m.run(inp, **kw).nchw().float().cpu()
+        ops.set_option("reg_epilogue", 0)
+        slab = m.run(inp, **kw).nchw().float().cpu()
+    finally:
+        ops.set_option("reg_epilogue", 1)
+        ops.set_option("specialised", was_s); ops.set_option("tall_min_tiles", was_t)
+        ops.set_precision("fp32")
+    assert torch.equal(reg, slab), f"register and slab epilogues differ: max |d| = {float((reg - slab).abs().max()):.3e} at {int((reg != slab).sum())} elements"
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    xb = torch.cat([_torch_act(x.to(bf).float(), pre, 0.05).to(bf).float() for x in xs], 1)
+    want = _torch_act(F.conv2d(xb, w, b, stride=stride, padding=k // 2), act, 0.05)
+    if res:
+        want = want + r.to(bf).float()
+    report_close("register epilogue vs torch", reg, want, 1.5e-2, 1.5e-2 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("segs,cout,k,stride,H,W,act,res", [
     ((128,), 128, 3, 1, 160, 320, 1, True),        # UNet bottleneck ResBlock shape class: four N-tiles per workgroup
     ((96,), 128, 5, 2, 512, 512, 0, False),        # stride 2 (even/odd column LDS layout) with four N-tiles
