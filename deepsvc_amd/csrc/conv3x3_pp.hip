@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
         for (int j = 0; j < PP_PFV; ++j) {
             const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
             const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PP_PFV - 1 || last_ok) && cok;   // padding reads zeros
-            pf[j] = buf_load16(rin, inb ? __umul24((unsigned)(base_pix + pp_pix[j]), ldb) + cb : OOB);
+            pf[j] = buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));   // no select of offsets: that becomes an exec-mask branch per load
         }
     };
     auto store_chunk = [&](uint4 (&pf)[PP_PFV]) {
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
         const int oy = t.oy0 + wg * MTW + m;                                          // scalar
         const int px = (r & 15) + 16 * half;
         const unsigned pix = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0) + px;
-        return (valid && oy < p.Ho && t.ox0 + px < p.Wo) ? __umul24(pix, (unsigned)ld * 2) + 32 * (r >> 4) + 16 * h : OOB;
+        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + 32 * (r >> 4) + 16 * h) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
     };
     uint4 res[MTW * NT * 2];
     auto load_res = [&](const TileOrg& t, bool valid) {
