@@ -33,16 +33,22 @@ int dsvc_conv3x3_direct_try(hipStream_t st, const dsvc_conv::ConvParams& p, cons
 // every workgroup of conv_mfma_kernel (tools/phase_probe.py reads them): [0] barrier before staging, [1] patch staging,
 // [2] weight staging, [3] barrier before the MFMAs, [4] MFMA phase, [5] epilogue, [6] whole kernel, [7] workgroups.
 __device__ unsigned long long g_phase[8];
-#define PROBE_STAMP(var) unsigned long long var = 0; if (probe) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define PROBE_STAMP(var) unsigned long long var = 0; if (probe) { var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   /* no vmcnt wait: prefetches stay in flight */
 #define PROBE_ADD(i, a, b) if (probe) ph[i] += (b) - (a);
 extern "C" int dsvc_dbg_phase_read(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+#define PROBE_FINISH                                                                                   \
+    { PROBE_STAMP(t_end)                                                                               \
+      if (probe) { ph[5] += t_end - t_epi;                                                             \
+                   for (int i = 0; i < 6; ++i) atomicAdd(&g_phase[i], ph[i]);                          \
+                   atomicAdd(&g_phase[6], t_end - t_begin); atomicAdd(&g_phase[7], 1ull); } }
 #else
 #define PROBE_STAMP(var)
 #define PROBE_ADD(i, a, b)
+#define PROBE_FINISH
 #endif
 
 namespace {
@@ -462,6 +468,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                 __builtin_amdgcn_raw_buffer_store_b128(s1, R.out, ((opix * p.out_ld + co0) * 2u + 32u) | pm, 0, 0);
             }
         }
+        PROBE_FINISH
         return;
     }
     constexpr int EPN = NT >= 2 ? 2 : 1;
@@ -492,15 +499,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             else run_epilogue<GPP, EPLD, 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);     // odd last row
         }
     }
-#ifdef DSVC_PHASE_PROBE
-    PROBE_STAMP(t_end)
-    if (probe) {
-        ph[5] += t_end - t_epi;
-        for (int i = 0; i < 6; ++i) atomicAdd(&g_phase[i], ph[i]);
-        atomicAdd(&g_phase[6], t_end - t_begin);
-        atomicAdd(&g_phase[7], 1ull);
-    }
-#endif
+    PROBE_FINISH
 }
 
 template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false>
