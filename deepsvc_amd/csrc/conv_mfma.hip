@@ -59,7 +59,9 @@ using namespace dsvc_conv;
 // stores (the slab epilogue -- accumulators through LDS, two extra barriers per pass -- is ~20 % of a workgroup's time on
 // the large convs, tools/phase_probe.py).  Taken for bf16 output, whole 32-channel tiles, act in {none, relu, lrelu},
 // at most one bf16 residual; everything else keeps the slab epilogue.
-template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false>
+// PF > 0 (with REGEPI, bf16 storage, one staging batch per chunk): the input patch of the NEXT channel chunk is prefetched
+// into PF registers per thread during the last MFMA phase of the current chunk, like the weights.
+template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false, int PF = 0>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KCE = CTraits<CT>::KCE, EPV = CTraits<CT>::EPV;
@@ -132,6 +134,55 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         }
     };
     w_issue(0, 0, true);
+    uint4 pv[PF > 0 ? PF : 1];
+    auto p_issue = [&](int ch2, bool any) {          // same-type (bf16) storage only; every lane masked when !any (branch-free)
+        if constexpr (PF > 0) {
+            int s2i = 0;
+            if (p.nseg > 1 && ch2 >= p.seg[1].chunk0) s2i = 1;
+            if (p.nseg > 2 && ch2 >= p.seg[2].chunk0) s2i = 2;
+            const ConvSeg& sg2 = p.seg[s2i];
+            const int c02 = (ch2 - sg2.chunk0) * KCE;
+            const rsrc_t rs = make_rsrc(sg2.ptr, sg2.bytes);
+            const unsigned pitch = (unsigned)sg2.ld * sizeof(CT);
+            const unsigned img0 = b_lo * sg2.bs_lo + b_hi * sg2.bs_hi;
+            const unsigned img = p.s2d ? img0 + (unsigned)(ch2 - sg2.chunk0) * 16u + ((unsigned)(q >> 1) * 2u * p.W + (unsigned)(q & 1)) * pitch
+                                       : img0 + c02 * (unsigned)sizeof(CT) + q * 16;
+            const unsigned pixstep = p.s2d ? 2u : 1u, rowstep = p.s2d ? 4u * p.W : (unsigned)p.W;
+            const bool qvalid = any && c02 + q * EPV < sg2.C;
+            int py = py0, px = px0;
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int iy = iy0 + py, ix = ix0 + px;
+                const bool inb = qvalid && pix0 + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                pv[j] = buf_load16(rs, (img + ((unsigned)iy * rowstep + (unsigned)ix * pixstep) * pitch) | (inb ? 0u : OOB));
+                px += dpx; py += dpy;
+                if (px >= PW) { px -= PW; ++py; }
+            }
+        }
+    };
+    auto p_commit = [&]() {
+        if constexpr (PF > 0) {
+            const float sl = p.pre_act == DSVC_ACT_RELU ? 0.f : (p.pre_act == DSVC_ACT_NONE ? 1.f : p.slope);
+            int py = py0, px = px0;
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                uint4 v = pv[j];
+                if (p.pre_act != DSVC_ACT_NONE) {
+                    unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
+                        u[k] = (unsigned)f32_to_bf16_bits(fmaxf(lo, lo * sl)) | ((unsigned)f32_to_bf16_bits(fmaxf(hi, hi * sl)) << 16);
+                    }
+                    v = make_uint4(u[0], u[1], u[2], u[3]);
+                }
+                if (pix0 + 64 * j < npatch) *(uint4*)(lds_a + lds_row(py, px) * ROWB + q * 16) = v;
+                px += dpx; py += dpy;
+                if (px >= PW) { px -= PW; ++py; }
+            }
+        }
+    };
+    p_issue(0, true);
 #ifdef DSVC_PHASE_PROBE
     const bool probe = tid == 0;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
@@ -151,7 +202,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         // ---- stage the input halo patch of this channel chunk ----
         // Loads of a batch are all issued before the first LDS store so their L2/HBM latencies overlap.
         bool staged = false;
-        if constexpr (FAST && sizeof(CT) == 2) {
+        if constexpr (PF > 0) { p_commit(); staged = true; }
+        if constexpr (PF == 0 && FAST && sizeof(CT) == 2) {
             // fp32 storage feeding the bf16 MFMA (the entropy scan's fp32 latents): two 16-B loads per quarter, batched like
             // the same-type path, rounded to bf16 (RNE, as pack_vec does) on the way into LDS
             if (sg.dtype == DSVC_F32) {
@@ -194,7 +246,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             }
         }
         if (staged) {
-        } else if constexpr (FAST) {  // storage type == compute type, 16-B aligned, whole chunks
+        } else if constexpr (FAST && PF == 0) {  // storage type == compute type, 16-B aligned, whole chunks
             constexpr int PB = 6;
             const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);      // out-of-image pixels read as zeros (bounds-checked loads)
             const unsigned pitch = (unsigned)sg.ld * sizeof(CT);
@@ -284,6 +336,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     }
                     const bool more_tg = tg0 + p.tapg < ntaps;
                     w_issue(more_tg ? ch : ch + 1, more_tg ? tg0 + p.tapg : 0, more_tg || ch + 1 < p.nchunks);
+                    // the next chunk's patch, behind the weights; issued (masked) at every tap group so the code stays straight-line --
+                    // VMEM returns in order, the real load of the last group lands last
+                    p_issue(ch + 1, !more_tg && ch + 1 < p.nchunks);
                 }
             } else {
                 // bounds-checked buffer loads, masked by the offset: a conditional global load per vector made hipcc wait for every
@@ -502,10 +557,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     PROBE_FINISH
 }
 
-template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false>
+template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false, int PF = 0>
 int launch_cfg(hipStream_t st, const ConvParams& p, int ngroups, size_t lds) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<CT, MT, NT, FAST, REGEPI>;
+    auto kern = conv_mfma_kernel<CT, MT, NT, FAST, REGEPI, PF>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
@@ -532,7 +587,7 @@ int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, in
     if constexpr (sizeof(CT) == 2) {
         if (p.regepi) {                       // register epilogue (see conv_mfma_kernel): large bf16 convs only
             if (MT == 4) return launch_cfg<CT, 4, 2, true, true>(st, p, ngroups, lds);
-            if (NT == 2) return launch_cfg<CT, 2, 2, true, true>(st, p, ngroups, lds);
+            if (NT == 2) return p.patchpf ? launch_cfg<CT, 2, 2, true, true, 6>(st, p, ngroups, lds) : launch_cfg<CT, 2, 2, true, true>(st, p, ngroups, lds);
             if (NT == 3) return launch_cfg<CT, 2, 3, true, true>(st, p, ngroups, lds);
             return launch_cfg<CT, 2, 4, true, true>(st, p, ngroups, lds);
         }
@@ -691,7 +746,11 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     // counters put the LDS at ~35 % busy and the MFMA pipe at 36 %, i.e. the kernel waits on barriers and staging latency
     // with two workgroups per CU, not on LDS bandwidth
     // (96 output channels: 16 rows spill -- 192 accumulator registers --, and a 12-row variant measured 237 vs 152 us)
-    if (MT == 2 && NT == 2 && fast && d->compute == DSVC_BF16 && d->stride == 1 && nblocks(4, NT) >= opt.tall_min_tiles) {
+    bool same_type = true;
+    for (int s = 0; s < d->nseg; ++s) same_type = same_type && p.seg[s].dtype == d->compute;
+    // 3x3 convs over bf16 storage take the patch-prefetch variant of the 8x32 tiling instead (64+64->64: 452 vs 466 us)
+    const bool pf_shape = opt.patch_prefetch && opt.reg_epilogue && same_type && d->kh == 3 && d->kw == 3 && d->out_dtype == DSVC_BF16;
+    if (MT == 2 && NT == 2 && fast && d->compute == DSVC_BF16 && d->stride == 1 && !pf_shape && nblocks(4, NT) >= opt.tall_min_tiles) {
         const size_t a4 = (size_t)(15 + d->kh) * (31 + d->kw) * ROWB;
         if (a4 + (size_t)d->kw * NT * 32 * ROWB <= 78 * 1024) MT = 4;           // still two workgroups per CU
     }
@@ -719,6 +778,10 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
                    d->shuffle == 1 && (d->Cout % 32) == 0 && al16(d->out, d->out_ld) && !d->res2 && !d->res1_scale &&
                    (!d->res1 || (d->res1_dtype == DSVC_BF16 && al16(d->res1, d->res1_ld))) &&
                    (d->act == DSVC_ACT_NONE || d->act == DSVC_ACT_RELU || (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f));
+    }
+    {   // patch prefetch variant: bf16 storage everywhere, one staging batch (<= 6 vectors per thread) per chunk
+        // (96 output channels: 256 registers with spills, 142 vs 129 us -- not taken)
+        p.patchpf = p.regepi && opt.patch_prefetch && MT == 2 && NT == 2 && same_type && PH * PW <= 6 * 64;
     }
     const size_t lds_epi = p.regepi ? 0 : (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;

@@ -53,9 +53,9 @@ int dsvc_device_count(void);
  * conv3x3_direct may take a launch, 0: generic kernel only), "pp", "ws", "conv1x1", "direct" (each 0/1),
  * "direct_max_pix", "ws_waves4", "ws_direct_store", "tall_min_tiles" (the generic kernel uses 16x32-pixel tiles for bf16
  * stride-1 convs with 64 output channels per group from this many tiles on; a huge value turns them off), "reg_epilogue" (1: the
- * generic kernel's LDS-free epilogue where it applies).  Defaults come from
+ * generic kernel's LDS-free epilogue where it applies), "patch_prefetch" (1: ... with the next chunk's input patch prefetched).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_DIRECT, DSVC_DIRECT_MAX_PIX, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
- * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI).
+ * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in bf16 mode they agree within the bf16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);

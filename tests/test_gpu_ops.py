@@ -280,6 +280,8 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
     ((32,), 64, 7, 1, 1, 120, 250, 0, 1, False),         # 7x7: tap groups of one kernel row
     ((96,), 64, 5, 2, 1, 400, 512, 0, 0, False),         # stride 2
     ((64,), 256, 3, 1, 1, 160, 320, 0, 2, False),        # two groups of four N-tiles
+    ((64, 32), 64, 3, 1, 1, 130, 300, 2, 2, True),       # 64 output channels, three chunks over two segments: patch prefetch, LeakyReLU on the way in
+    ((32,), 64, 3, 1, 2, 90, 200, 0, 1, False),          # ... a single chunk (nothing to prefetch), batch 2
 ])
 def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, H, W, pre, act, res):
     """The generic kernel's LDS-free epilogue (MFMA operands swapped, one 32-lane swap, two 16-byte stores per lane and
@@ -303,6 +305,10 @@ def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, 
         inp = ins if len(ins) > 1 else ins[0]
         ops.set_option("reg_epilogue", 1)
         reg = m.run(inp, **kw).nchw().float().cpu()
+        was_p = ops.set_option("patch_prefetch", 0)          # the same variant without the input-patch prefetch
+        reg_nopf = m.run(inp, **kw).nchw().float().cpu()
+        ops.set_option("patch_prefetch", was_p)
+        assert torch.equal(reg, reg_nopf), "patch prefetch changes the result"
         ops.set_option("reg_epilogue", 0)
         slab = m.run(inp, **kw).nchw().float().cpu()
     finally:
@@ -367,7 +373,7 @@ def test_conv_tall_tile_variant(segs, cout, k, B, H, W, pre, act, res):
     torch.manual_seed(sum(segs) + cout + W)
     bf = torch.bfloat16
     ops.set_precision("bf16")
-    was_s, was_t = ops.set_option("specialised", 0), ops.set_option("tall_min_tiles", 1)
+    was_s, was_t, was_p = ops.set_option("specialised", 0), ops.set_option("tall_min_tiles", 1), ops.set_option("patch_prefetch", 0)
     try:
         m = Conv2d(sum(segs), cout, k, 1, k // 2).to(DEV)
         xs = [torch.randn(B, c, H, W) for c in segs]
@@ -380,7 +386,7 @@ def test_conv_tall_tile_variant(segs, cout, k, B, H, W, pre, act, res):
         ops.set_option("tall_min_tiles", 1 << 30)
         flat = m.run(ins if len(ins) > 1 else ins[0], **kw).nchw().float().cpu()
     finally:
-        ops.set_option("specialised", was_s); ops.set_option("tall_min_tiles", was_t)
+        ops.set_option("specialised", was_s); ops.set_option("tall_min_tiles", was_t); ops.set_option("patch_prefetch", was_p)
         ops.set_precision("fp32")
     assert torch.equal(tall, flat), f"16-row and 8-row tilings differ: max |d| = {float((tall - flat).abs().max()):.3e}"
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
