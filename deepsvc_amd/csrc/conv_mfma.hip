@@ -780,7 +780,8 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
                    (d->act == DSVC_ACT_NONE || d->act == DSVC_ACT_RELU || (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f));
     }
     {   // patch prefetch variant: bf16 storage everywhere, one staging batch (<= 6 vectors per thread) per chunk
-        // (96 output channels: 256 registers with spills, 142 vs 129 us -- not taken)
+        // (96 output channels: 256 registers with spills, 142 vs 129 us; with the k-step fragment pipeline to free registers 137 vs
+        //  121 us for the tap-level pipeline without patch prefetch -- not taken)
         p.patchpf = p.regepi && opt.patch_prefetch && MT == 2 && NT == 2 && same_type && PH * PW <= 6 * 64;
     }
     const size_t lds_epi = p.regepi ? 0 : (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
