@@ -224,7 +224,7 @@ def main():
                             "(arithmetic intensity 288 FLOP/B sits at the machine balance 2500/8 = 312, hence both fractions)"}
         summ = harness.summarise(table)
         line = {
-            "metric": "encode+decode fps @1080p", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": "encode+decode fps @1080p" if (h, w) == (1080, 1920) else f"encode+decode fps @{w}x{h}", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{w}x{h} (padded {W_pad}x{H_pad}) GOP={GOP} P-frames, W0 synthetic PSNR weight set, "
