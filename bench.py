@@ -1,32 +1,47 @@
 #!/usr/bin/env python3
 """bench.py -- encode+decode frames/s of the DeepSVC P-frame hot path at 1080p (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|bf16] [--size HxW]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-           bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--size HxW] [--config 2|3] [--lanes L]
 
-A "step" = one P-frame: `DeepSVC.compress` + `DeepSVC.decompress` on a 1920x1080 frame (padded to 1088x1920),
-frames chained inside GOPs of 7 (1 given key frame + 6 P-frames, BASELINE.json configs[1]); synthetic septuplets
-and the W0 weight set (deepsvc_amd/synth.py) are resident in HBM before the timed region.  Each rank codes its
-own GOPs (weak scaling, no data-path collective); one metrics gather at the end.
-Prints ONE JSON line on rank 0 (contract in the task description): value = frames of all ranks / max-over-ranks time.
-Extra objects: "roofline" (dominant kernel = 3x3 64->64 conv at full resolution, per-launch HIP-event timing
-inside the timed region) and "cpu_baseline" (the CPU oracle timed on this host on a bounded 256x256 sample).
+`--gpus N` with N > 1 launches N ranks itself (one fresh child process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, before
+the parent touches the GPU; the parent only relays rank 0's line); under `python -m torch.distributed.run ... bench.py --gpus N`
+the ranks are already there and WORLD_SIZE must equal N.
+
+A "step" = one frame on every GOP lane of a rank: `DeepSVC.compress` + `DeepSVC.decompress` on a 1920x1080 frame (padded to
+1088x1920), frames chained inside GOPs of 7 (1 given key frame + 6 P-frames, BASELINE.json configs[1]); `--config 3`: GOP = 12
+whose key frame is coded by the I-frame codec `ICIP2020ResB` (configs[2]).  Synthetic septuplets and the W0 weight sets
+(deepsvc_amd/synth.py) are resident in HBM before the timed region.  Each rank codes its own GOPs (weak scaling, no data-path
+collective); one metrics gather at the end.
+
+Prints ONE JSON line on rank 0 (contract in the task description): value = frames of all ranks / max-over-ranks time of the
+headline leg (bf16 MFMA mode, `--lanes` GOP pipelines in flight per GPU).  Further legs of the same run, each barrier-bracketed
+and timed the same way, are reported inside the line:
+  "lanes1"      the same mode with ONE GOP in flight (strictly sequential frames): fps, and the source of `roofline` -- HIP events
+                around every launch of the dominant conv shape in that region are the kernel's own durations (with several lanes
+                in flight a launch time-shares the GPU with the other lanes' kernels; that figure is kept as `roofline.timeshared_*`);
+  "parity_mode" fp32 mode (fp32 storage, fp32 MFMA): the reference's arithmetic; bitstreams byte-identical to the reference's
+                at the golden sizes (tests/test_gpu_parity.py); fps + its own roofline against the 157.3 TFLOP/s fp32 MFMA peak;
+  "bf16_vs_f32" rate / PSNR / un-clamped tensor deltas of bf16 mode against fp32 mode on the same frames, measured in this run;
+  "cpu_baseline" (+ "cpu_baseline_1thread") the CPU oracle timed on this host (N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GOP = 7
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / bf16 MFMA peaks
-FLOP_PER_PX_GOP7 = 8.571e6                           # GOP=7 mean conv FLOP per padded pixel per P-frame
+HBM_PEAK = 8.0e12                                    # B/s
+# conv FLOP per padded pixel, reference structure (incl. its encoder-side recomputation)
+FLOP_PER_PX = {2: 8.571e6,      # GOP = 7: mean over the 6 P-frames (first P 8.453e6, steady-state 8.594e6)
+               3: 8.076e6}      # GOP = 12 with the intra-coded key frame: mean over all 12 frames
+GOP_OF = {2: 7, 3: 12}
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")
 
 
 def parse():
@@ -37,42 +52,92 @@ def parse():
     ap.add_argument("--lanes", type=int, default=4, help="independent GOP pipelines in flight per GPU (1 = strictly sequential frames)")
     ap.add_argument("--precision", default=os.environ.get("DSVC_PRECISION", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--size", default="1080x1920")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3], help="BASELINE.json configs[1] (GOP=7, key frame given) or configs[2] (GOP=12, I-frame codec)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="headline leg only (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-frames", type=int, default=6)
     return ap.parse_args()
 
 
-def cpu_baseline(sample, H_pad, W_pad):
-    """The oracle (CPU restatement of the reference path, oracle/) timed on this host: one chained pair of
-    P-frames at sample x sample, all host threads; scaled to 1080p by the pixel ratio (cost is per-pixel:
-    SURVEY section 8d).  Baseline only -- never the measured path."""
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun
+# ------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Spawn args.gpus fresh child processes (this interpreter, this script, same flags), one per GPU, before this process makes
+    any GPU call; relay rank 0's JSON line; exit non-zero if any rank fails.  Never re-execs a process that touched the GPU."""
+    import torch                                   # device_count() does not initialise the GPU on this image
+    n = args.gpus
+    rehearsal = bool(os.environ.get("DSVC_BENCH_REHEARSAL"))
+    have = torch.cuda.device_count()
+    if have < n and not rehearsal:
+        sys.exit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (DSVC_BENCH_REHEARSAL=1 runs the ranks on one GPU over gloo)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        sys.exit(f"bench.py: rank exit codes {codes}")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle on the host cores
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sample, n_frames, threads, H_pad, W_pad):
+    """The oracle (CPU restatement of the reference path, oracle/) timed on this host: `n_frames` chained P-frames
+    (compress + decompress each; state chaining of test_video.py:342-369) at sample x sample with `threads` torch threads
+    (1 = the reference harness's own setting, test_video.py:16); scaled to the padded frame by the pixel ratio (the cost is
+    per-pixel: SURVEY section 8d).  Baseline only -- never the measured path."""
+    import torch
     from deepsvc_amd import synth
     from oracle.codec import DeepSVCOracle
-    model = synth.make_model("W0")
-    orc = DeepSVCOracle(model.state_dict())
-    orc.update()
-    fr = synth.make_frames(sample, sample, 3)
-    ref, feat = fr[0], None
-    t_tot, n = 0.0, 0
-    for t in (1, 2):
-        sm = synth.make_sm_fea(sample, sample, t)
-        t0 = time.perf_counter()
-        mv, res = orc.compress(ref, fr[t], sm, feat)
-        feat, ref, _, _ = orc.decompress(ref, mv, res, sm, feat)
-        t_tot += time.perf_counter() - t0
-        n += 1
-    fps_sample = n / t_tot
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        orc = DeepSVCOracle(synth.make_model("W0").state_dict())
+        orc.update()
+        fr = synth.make_frames(sample, sample, n_frames + 1)
+        ref, feat, per = fr[0], None, []
+        for t in range(1, n_frames + 1):
+            sm = synth.make_sm_fea(sample, sample, t)
+            t0 = time.perf_counter()
+            mv, res = orc.compress(ref, fr[t], sm, feat)
+            feat, ref, _, _ = orc.decompress(ref, mv, res, sm, feat)
+            per.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+    t_tot = sum(per)
     scale = (sample * sample) / float(H_pad * W_pad)
-    return {"value": fps_sample * scale, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} chained P-frames (compress+decompress) at {sample}x{sample}, {t_tot:.1f} s of CPU, "
-                      f"scaled by pixel ratio to {H_pad}x{W_pad}; oracle = PyTorch-CPU restatement of the reference"}
+    return {"value": n_frames / t_tot * scale, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n_frames} chained P-frames (compress+decompress) at {sample}x{sample}, {t_tot:.1f} s of CPU "
+                      f"(per frame min {min(per):.2f} / max {max(per):.2f} s), scaled by pixel ratio to {H_pad}x{W_pad}; "
+                      f"oracle = PyTorch-CPU restatement of the reference, pinned byte for byte by the reference's golden vectors"}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         if os.environ.get("DSVC_BENCH_REHEARSAL"):      # N ranks sharing the ONE GPU of a development box: gloo, all on cuda:0
@@ -80,28 +145,18 @@ def main():
             local_rank = 0
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        ranks_seen = dist.get_world_size()
+        assert ranks_seen == args.gpus, f"process group has {ranks_seen} ranks, --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
     from deepsvc_amd import harness, ops, synth
     from deepsvc_amd.modules import pad
-    ops.set_precision(args.precision)
     h, w = (int(v) for v in args.size.lower().split("x"))
     H_pad, W_pad = -(-h // 64) * 64, -(-w // 64) * 64
-
-    # L independent GOP pipelines ("lanes") per GPU: GOPs are independent units of work (harness.py), and one GOP alone
-    # leaves the GPU idle ~20 % of a frame while the host range-decodes each scan level (sequential by bitstream format).
-    # Each lane = its own model instance (weights, workspaces, HIP graphs), stream and thread, coding its own GOPs; a
-    # step codes one P-frame on EVERY lane (a batch of L frames), so the line reports L*K frames per rank.
-    lanes = []
-    for ln in range(args.lanes):
-        m = synth.make_model("W0")
-        m.update(force=True)
-        seed = 1234 + rank * 16 + ln
-        lanes.append({
-            "model": m.to(dev), "stream": torch.cuda.Stream(dev), "t": 0, "ref": None, "feature": None, "rows": [], "id": ln,
-            "frames": [f.to(dev) for f in synth.make_frames(h, w, GOP, seed=seed)],
-            "sm": [None] + [synth.make_sm_fea(H_pad, W_pad, t, seed=seed).to(dev) for t in range(1, GOP)]})
+    GOP = GOP_OF[args.config]
+    intra = args.config == 3
+    conv_flop = 2.0 * H_pad * W_pad * 64 * 64 * 9
 
     def barrier():
         if world > 1:
@@ -109,16 +164,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    # L independent GOP pipelines ("lanes") per GPU: GOPs are independent units of work (harness.py), and one GOP alone
+    # leaves the GPU idle ~20 % of a frame while the host range-decodes each scan level (sequential by bitstream format).
+    # Each lane = its own model instance (weights, workspaces, HIP graphs), stream and thread, coding its own GOPs; a
+    # step codes one frame on EVERY lane (a batch of L frames), so the line reports L*K frames per rank.
+    def make_lane(ln, precision):
+        ops.set_precision(precision)
+        m = synth.make_model("W0")
+        m.update(force=True)
+        im = None
+        if intra:
+            im = synth.make_icodec("W0")
+            im.update(force=True)
+            im = im.to(dev)
+        seed = 1234 + rank * 16 + ln
+        return {"model": m.to(dev), "imodel": im, "stream": torch.cuda.Stream(dev), "t": 0, "ref": None, "feature": None, "rows": [],
+                "id": ln, "frames": [f.to(dev) for f in synth.make_frames(h, w, GOP, seed=seed)],
+                "sm": [None] + [synth.make_sm_fea(H_pad, W_pad, t, seed=seed).to(dev) for t in range(1, GOP)]}
+
     def step(L, record):
+        """One frame of lane L's GOP chain.  config 2: P-frames 1..6 (key frame given); config 3: frame 0 is coded by the
+        I-frame codec and counts as a step, then P-frames 1..11."""
         model, frames, sm_feas = L["model"], L["frames"], L["sm"]
-        t = L["t"] % (GOP - 1) + 1                    # P-frame index inside the GOP: 1..6
-        if t == 1:
+        per_gop = GOP if intra else GOP - 1
+        t = L["t"] % per_gop + (0 if intra else 1)
+        if t == 0:
+            key = pad(frames[0], 64)
+            enc = L["imodel"].compress(key)
+            recon = L["imodel"].decompress(enc["strings"], enc["shape"])["x_hat"]
+            if record:
+                L["rows"].append([float(rank * 1000 + L["id"] * 100 + L["t"] // per_gop), 0.0, 0.0,
+                                  harness.strings_bytes(enc) * 8.0 / (h * w), recon, key])
+            L["ref"], L["feature"] = recon, None
+            L["t"] += 1
+            return
+        if t == 1 and not intra:
             L["ref"], L["feature"] = pad(frames[0], 64), None
         cur = pad(frames[t], 64)
         mv_enc, res_enc = model.compress(L["ref"], cur, sm_feas[t], L["feature"])
         feature, recon, warped, predict = model.decompress(L["ref"], mv_enc, res_enc, sm_feas[t], L["feature"])
         if record:
-            L["rows"].append([float(rank * 1000 + L["id"] * 100 + L["t"] // (GOP - 1)), float(t),
+            L["rows"].append([float(rank * 1000 + L["id"] * 100 + L["t"] // per_gop), float(t),
                               harness.strings_bytes(mv_enc) * 8.0 / (h * w), harness.strings_bytes(res_enc) * 8.0 / (h * w),
                               recon, cur])
         L["ref"], L["feature"] = recon, feature
@@ -131,112 +224,177 @@ def main():
                 step(L, record)
             L["stream"].synchronize()
 
-    # Warm-up, one lane at a time: weight packing and HIP-graph capture need a quiescent device (no other thread
-    # launching).  W steps per lane; with several lanes a lane's graphs are only final once EVERY lane has packed its
-    # weights, so lanes whose graphs are not in place after W steps get the few extra untimed steps they need.
-    for w_i in range(max(args.warmup, 1)):
-        for L in lanes:
-            run_lane(L, 1, False)
-    for _ in range(4):
-        todo = [L for L in lanes if not L["model"].graphs_ready(1, H_pad, W_pad, dev)]
-        if not todo:
-            break
-        for L in todo:
-            run_lane(L, 1, False)
-    # the roofline leg: time every launch of the dominant conv shape inside the timed region
-    full_res = lambda pc, x0: (pc.kh == 3 and pc.stride == 1 and pc.segC == (64,) and pc.Cout == 64 and x0.H == H_pad and x0.W == W_pad)
-    ops.PROFILE = {"match": full_res, "pairs": []}
-    barrier()
-    t0 = time.perf_counter()
-    if len(lanes) == 1:
-        run_lane(lanes[0], args.steps, True)
-    else:
-        import threading
-        threads = [threading.Thread(target=run_lane, args=(L, args.steps, True)) for L in lanes]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    rows = [r for L in lanes for r in L["rows"]]
-    # the same launch on an otherwise idle GPU (after the timed region): with several lanes the in-region durations
-    # include time-sharing with the other lanes' kernels, so both figures are reported
-    iso_ms = None
-    if rank == 0:
-        from deepsvc_amd.modules import Conv2d
-        st = ops.RT.storage
-        conv = Conv2d(64, 64, 3, 1, 1).to(dev)
-        xin = ops.Act(torch.randn((1, H_pad, W_pad, 64), device=dev).to(st))
-        xout = ops.new_act(1, H_pad, W_pad, 64, st, dev)
-        for _ in range(3):
-            conv.run(xin, xout)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(10):
-            conv.run(xin, xout)
-        e1.record()
-        torch.cuda.synchronize()
-        iso_ms = e0.elapsed_time(e1) / 10
+    def warm(lanes, n):
+        """One lane at a time: weight packing and HIP-graph capture need a quiescent device (no other thread launching).
+        With several lanes a lane's graphs are only final once EVERY lane has packed its weights, so lanes whose graphs are
+        not in place after n steps get the few extra untimed steps they need."""
+        for _ in range(max(n, 1) + (1 if intra else 0)):
+            for L in lanes:
+                run_lane(L, 1, False)
+        for _ in range(4):
+            todo = [L for L in lanes if not L["model"].graphs_ready(1, H_pad, W_pad, dev)]
+            if not todo:
+                break
+            for L in todo:
+                run_lane(L, 1, False)
+        for L in lanes:                      # every timed region starts at a GOP boundary
+            L["t"] = 0
 
-    # metrics (outside the timed region)
+    full_res = lambda pc, x0: (pc.kh == 3 and pc.stride == 1 and pc.segC == (64,) and pc.Cout == 64 and x0.H == H_pad and x0.W == W_pad)
+
+    def timed(lanes, n):
+        """Barrier + synchronize on both sides; every launch of the dominant conv shape inside is bracketed by HIP events on
+        its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank])"""
+        ops.PROFILE = {"match": full_res, "pairs": []}
+        barrier()
+        t0 = time.perf_counter()
+        if len(lanes) == 1:
+            run_lane(lanes[0], n, True)
+        else:
+            import threading
+            threads = [threading.Thread(target=run_lane, args=(L, n, True)) for L in lanes]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof, ops.PROFILE = ops.PROFILE, None
+        return max_over_ranks(elapsed), [a.elapsed_time(b) for a, b in prof["pairs"]]
+
+    def roofline_of(durs, precision, extra=None):
+        if not durs:
+            return None
+        avg_ms = sum(durs) / len(durs)
+        achieved = conv_flop / (avg_ms * 1e-3) / 1e12
+        esz = 2 if precision == "bf16" else 4
+        r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision],
+             "traffic": None,
+             "kernel": f"3x3 s1 64->64 conv @{H_pad}x{W_pad}, all epilogue variants ({'conv3x3_pp_kernel' if precision == 'bf16' else 'conv_mfma_kernel'})",
+             "launches": len(durs), "avg_ms": avg_ms, "min_ms": min(durs),
+             "algorithmic_flop": conv_flop, "algorithmic_bytes": 2.0 * H_pad * W_pad * 64 * esz,
+             "hbm_view": {"achieved_GBps": 2.0 * H_pad * W_pad * 64 * esz / (avg_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK / 1e9,
+                          "frac": 2.0 * H_pad * W_pad * 64 * esz / (avg_ms * 1e-3) / HBM_PEAK,
+                          "note": "input + output once (a residual operand, where a variant has one, adds 50 %)"}}
+        r.update(extra or {})
+        return r
+
+    # ---- headline leg ------------------------------------------------------------------------------------------------
+    lanes = [make_lane(ln, args.precision) for ln in range(args.lanes)]
+    warm(lanes, args.warmup)
+    t_max, durs_shared = timed(lanes, args.steps)
+    rows = [r for L in lanes for r in L["rows"]]
+    hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30
+
+    side = not args.no_side_legs
+    lanes1 = parity = deltas = None
+    durs_own = durs_shared if args.lanes == 1 else None
+    if side and args.lanes > 1:
+        # ---- the same mode, ONE GOP in flight: the kernel's own durations ----
+        for L in lanes:
+            L["rows"] = []
+        n1 = GOP if intra else GOP - 1
+        t1, durs_own = timed(lanes[:1], n1)
+        lanes1 = {"value": n1 * world / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1000.0 * t1 / n1, "gop_lanes": 1}
+    if side and args.precision == "bf16" and not intra:
+        # ---- reference precision: fp32 mode, one GOP in flight ----
+        ops.set_precision("fp32")
+        try:
+            f32 = make_lane(0, "fp32")
+            warm([f32], 2)
+            n32 = GOP - 1
+            t32, durs32 = timed([f32], n32)
+            parity = {"dtype": "f32", "value": n32 * world / t32, "unit": "frames/s", "steps": n32, "ms_per_step": 1000.0 * t32 / n32,
+                      "gop_lanes": 1, "roofline": roofline_of(durs32, "fp32"),
+                      "whole_frame_tflops": n32 / t32 * FLOP_PER_PX[2] * H_pad * W_pad / 1e12,
+                      "note": "fp32 storage + v_mfma_f32_32x32x2_f32: the reference's arithmetic (PyTorch fp32); bitstreams byte-identical "
+                              "to the reference's golden strings at 64/128/256 px (tests/test_gpu_parity.py)"}
+            if rank == 0:
+                # ---- bf16 mode vs fp32 mode on the same frames (each chained on its own decoded state), un-clamped tensors ----
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import parity_util as PU
+                b16 = lanes[0]
+                per = []
+                st = {"bf16": (pad(b16["frames"][0], 64), None), "fp32": (pad(b16["frames"][0], 64), None)}
+                for t in (1, 2, 3):
+                    cur, sm = pad(b16["frames"][t], 64), b16["sm"][t]
+                    got = {}
+                    for mode, L in (("bf16", b16), ("fp32", f32)):
+                        ops.set_precision(mode)
+                        ref, feat = st[mode]
+                        L["model"].debug_taps = {}
+                        mv, res = L["model"].compress(ref, cur, sm, feat)
+                        feat2, recon, _, _ = L["model"].decompress(ref, mv, res, sm, feat)
+                        taps, L["model"].debug_taps = L["model"].debug_taps, None
+                        got[mode] = (harness.strings_bytes(mv) + harness.strings_bytes(res), PU.psnr(harness.crop(recon, (h, w)), b16["frames"][t]),
+                                     taps["recon"].float(), feat2.float())
+                        st[mode] = (recon, feat2)
+                    (nb, pb, rb, fb), (nf, pf, rf, ff) = got["bf16"], got["fp32"]
+                    per.append({"frame": t, "bytes_bf16": nb, "bytes_f32": nf, "dbpp_pct": 100.0 * (nb - nf) / nf, "psnr_f32_db": pf,
+                                "dpsnr_db": pb - pf, "recon_rel_l2": float((rb - rf).norm() / rf.norm()),
+                                "feature_rel_l2": float((fb - ff).norm() / ff.norm()),
+                                "psnr_bf16_vs_f32_recon_db": PU.psnr(rb, rf),
+                                "clamped_frac_f32": float(((rf < 0) | (rf > 1)).float().mean())})
+                worst = lambda k: max((abs(p[k]) for p in per))
+                deltas = {"frames": per, "dbpp_pct": worst("dbpp_pct"), "dpsnr_db": worst("dpsnr_db"), "feature_rel_l2": worst("feature_rel_l2"),
+                          "recon_rel_l2": worst("recon_rel_l2"),
+                          "note": "worst |delta| over 3 chained P-frames of lane 0's GOP, each mode chained on its own decoded state; "
+                                  "un-clamped reconstruction and decoded 64-channel feature; north_star tolerance: 1 % bpp, 0.05 dB"}
+        finally:
+            ops.set_precision(args.precision)
+
+    # ---- metrics (outside the timed regions) -------------------------------------------------------------------------
     metric_rows = []
     for unit, t, bmv, bres, recon, cur in rows:
-        mse = float(((recon - cur) ** 2).mean())
+        mse = float(((harness.crop(recon, (h, w)) - harness.crop(cur, (h, w))) ** 2).mean())
         metric_rows.append([unit, t, bmv, bres, -10 * torch.log10(torch.tensor(mse)).item() if mse > 0 else 99.0, 0.0, 0.0, 0.0, 0.0, 0.0])
     table = harness.gather_rows(metric_rows, dev, world)
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    t_max = float(t_max)
 
     if rank == 0:
         total_frames = args.steps * world * args.lanes
         fps = total_frames / t_max
-        durs = [a.elapsed_time(b) for a, b in prof["pairs"]]          # ms, HIP events on the launch stream
-        conv_flop = 2.0 * H_pad * W_pad * 64 * 64 * 9
-        roof = None
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")
-        if args.precision == "bf16" and (h, w) == (1080, 1920) and os.path.exists(pmc_file):
-            with open(pmc_file) as f:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (cannot run in-process)
-                traffic = json.load(f)["hbm_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_dominant_kernel_pmc.json (2*FETCH_SIZE + WRITE_SIZE per launch, MI355X_MICROARCH.md HBM correction)"
-        if durs:
-            avg_ms = sum(durs) / len(durs)
-            achieved = conv_flop / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes": 2.0 * H_pad * W_pad * 64 * (2 if args.precision == "bf16" else 4),
-                    "kernel": "3x3 s1 64->64 conv @%dx%d (bf16: conv3x3_pp_kernel, fp32: conv_mfma_kernel)" % (H_pad, W_pad),
-                    "launches": len(durs), "avg_ms": avg_ms, "isolated_avg_ms": iso_ms,
-                    "isolated_achieved": conv_flop / (iso_ms * 1e-3) / 1e12 if iso_ms else None,
-                    "isolated_frac": conv_flop / (iso_ms * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision] if iso_ms else None,
-                    "isolated_hbm_frac": (2.0 * H_pad * W_pad * 64 * (2 if args.precision == "bf16" else 4) / (iso_ms * 1e-3) / 8e12) if iso_ms else None,
-                    "concurrent_lanes": args.lanes,
-                    "note": "achieved/frac/avg_ms: HIP events around every launch of this shape inside the timed region -- with "
-                            "concurrent_lanes > 1 the launch shares the GPU with the other lanes' kernels, so its duration (and the "
-                            "rocprofv3 per-kernel average of the same command) is ~lanes x the kernel's own time; isolated_*: the same "
-                            "launch on an idle GPU after the timed region = what `--lanes 1` and its rocprofv3 summary show "
-                            "(arithmetic intensity 288 FLOP/B sits at the machine balance 2500/8 = 312, hence both fractions)"}
+        traffic = None
+        extra = {}
+        if args.precision == "bf16" and (h, w) == (1080, 1920) and os.path.exists(PMC_FILE):
+            with open(PMC_FILE) as f:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (cannot run in-process)
+                pmc = json.load(f)
+            traffic = pmc.get("hbm_bytes_per_launch_corrected")
+            extra["traffic_source"] = "profiles/r02_dominant_kernel_pmc.json (separate rocprofv3 --pmc passes of `bench.py --lanes 1`, per launch, corrected per MI355X_MICROARCH.md)"
+        roof = roofline_of(durs_own, args.precision, extra)
+        if roof is not None:
+            roof["traffic"] = traffic
+            roof["measured_in"] = "lanes1 leg (one GOP in flight): HIP events on the launch stream around every launch of this shape" if args.lanes > 1 and side \
+                else "timed region (one GOP in flight): HIP events on the launch stream around every launch of this shape"
+            if args.lanes > 1 and durs_shared:
+                ts = sum(durs_shared) / len(durs_shared)
+                roof["timeshared_avg_ms"] = ts
+                roof["timeshared_frac"] = conv_flop / (ts * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision]
+                roof["timeshared_note"] = f"the same launches inside the {args.lanes}-lane headline region: a launch shares the GPU with the other lanes' kernels, so this is not the kernel's cost"
         summ = harness.summarise(table)
+        name = "encode+decode fps @1080p" if (h, w) == (1080, 1920) else f"encode+decode fps @{w}x{h}"
         line = {
-            "metric": "encode+decode fps @1080p" if (h, w) == (1080, 1920) else f"encode+decode fps @{w}x{h}", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": name, "value": fps, "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{w}x{h} (padded {W_pad}x{H_pad}) GOP={GOP} P-frames, W0 synthetic PSNR weight set, "
-                                   f"compress+decompress per frame, GOPs sharded across ranks, {args.lanes} independent GOP lane(s) in flight per GPU "
-                                   f"(one step = one P-frame on every lane)", "precision": args.precision, "gop_lanes": args.lanes,
-                       "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 2**30,
-                       "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
-                       "whole_frame_tflops": fps * FLOP_PER_PX_GOP7 * H_pad * W_pad / 1e12 / world},
+            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {w}x{h} (padded {W_pad}x{H_pad}) GOP={GOP} "
+                                   + ("(key frame coded by ICIP2020ResB + 11 P-frames), " if intra else "(key frame given + 6 P-frames), ")
+                                   + f"W0 synthetic PSNR weight set, compress+decompress per frame, GOPs sharded across ranks, {args.lanes} independent "
+                                     f"GOP lane(s) in flight per GPU (one step = one frame on every lane)",
+                       "precision": args.precision, "gop_lanes": args.lanes, "frames_per_step": args.lanes * world,
+                       "hbm_peak_gb": hbm_peak_gb, "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
+                       "whole_frame_tflops": fps * FLOP_PER_PX[args.config] * H_pad * W_pad / 1e12 / world},
             "roofline": roof,
         }
+        if lanes1 is not None:
+            line["lanes1"] = lanes1
+        if parity is not None:
+            line["parity_mode"] = parity
+        if deltas is not None:
+            line["bf16_vs_f32"] = deltas
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, H_pad, W_pad)
+            import torch as _t
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_frames, _t.get_num_threads(), H_pad, W_pad)
+            line["cpu_baseline_1thread"] = cpu_baseline(args.cpu_sample, args.cpu_frames, 1, H_pad, W_pad)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

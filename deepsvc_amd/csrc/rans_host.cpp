@@ -92,6 +92,23 @@ inline void push_bypass(Encoder* e, uint32_t nibble) {      // caller guarantees
 bool table_ok(const dsvc_cdf_table* t) {
     return t && t->cdf && t->cdf_length && t->offset && t->rows > 0 && t->stride > 1;
 }
+
+// Every row must be a proper 16-bit CDF over its cdf_length entries: row[0] = 0, strictly increasing (no zero-frequency
+// symbol: the encoder's (freq-1)<<16 packing and the decoder's forward scan both rely on it), row[len-1] = 65536.  Tables
+// come from checkpoint buffers (entropy_models.host_tables), so they are validated, not trusted; a few hundred thousand
+// integer compares per call against >= 10^5 coded symbols.
+int rows_valid(const dsvc_cdf_table* t, const char* who) {
+    for (int r = 0; r < t->rows; ++r) {
+        const int32_t len = t->cdf_length[r];
+        DSVC_REQUIRE(len >= 2 && len <= t->stride, "%s: cdf_length[%d] = %d invalid (stride %d)", who, r, len, (int)t->stride);
+        const int32_t* row = t->cdf + (int64_t)r * t->stride;
+        DSVC_REQUIRE(row[0] == 0 && row[len - 1] == (1 << kPrecision), "%s: cdf row %d does not span [0, 65536]", who, r);
+        int bad = 0;
+        for (int32_t i = 1; i < len; ++i) bad |= row[i] <= row[i - 1];
+        DSVC_REQUIRE(!bad, "%s: cdf row %d is not strictly increasing (zero-frequency symbol)", who, r);
+    }
+    return DSVC_OK;
+}
 }  // namespace
 
 extern "C" int dsvc_rans_encoder_create(void** enc) {
@@ -110,10 +127,10 @@ extern "C" int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, 
     Encoder* e = (Encoder*)enc;
     e->nbytes = -1;
     // validation hoisted out of the symbol loop: the table once, the indexes in one vectorisable pass
-    for (int r = 0; r < t->rows; ++r) {
-        const int32_t max_value = t->cdf_length[r] - 2;
-        DSVC_REQUIRE(max_value >= 0 && max_value + 1 < t->stride, "rans_encode: cdf_length[%d] invalid", r);
-    }
+    // (a table that carries a LUT was validated row by row when dsvc_cdf_build_lut made it)
+    if (!t->lut) { if (int rc = rows_valid(t, "rans_encode")) return rc; }
+    for (int r = 0; r < t->rows; ++r)
+        DSVC_REQUIRE(t->cdf_length[r] >= 2 && t->cdf_length[r] <= t->stride, "rans_encode: cdf_length[%d] invalid", r);
     {
         uint32_t worst = 0;
         for (int64_t i = 0; i < n; ++i) worst |= (uint32_t)indexes[i] >= (uint32_t)t->rows ? 1u : 0u;
@@ -203,10 +220,10 @@ extern "C" int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap) {
 
 extern "C" int dsvc_cdf_build_lut(const dsvc_cdf_table* t, uint16_t* lut_out) {
     DSVC_REQUIRE(table_ok(t) && lut_out, "cdf_build_lut: bad argument");
+    if (int rc = rows_valid(t, "cdf_build_lut")) return rc;
     for (int r = 0; r < t->rows; ++r) {
         const int32_t* row = t->cdf + (int64_t)r * t->stride;
         const int32_t len = t->cdf_length[r];
-        DSVC_REQUIRE(len >= 2 && len <= t->stride, "cdf_build_lut: cdf_length[%d] invalid", r);
         int32_t s = 0;
         for (int b = 0; b < 256; ++b) {
             const uint32_t cf = (uint32_t)b << 8;
@@ -240,6 +257,7 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
         if (worst)
             for (int64_t i = 0; i < n; ++i)
                 DSVC_REQUIRE(indexes[i] >= 0 && indexes[i] < t->rows, "rans_decode: cdf index %d out of range at %lld", indexes[i], (long long)i);
+        if (!t->lut) { if (int rc = rows_valid(t, "rans_decode")) return rc; }
         for (int r = 0; r < t->rows; ++r)
             DSVC_REQUIRE(t->cdf_length[r] >= 2 && t->cdf_length[r] <= t->stride, "rans_decode: cdf_length[%d] invalid", r);
     }
@@ -260,7 +278,7 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
         int32_t s;
         if (lut) {
             s = lut[(size_t)ci * 256 + (cf >> 8)];
-            while ((uint32_t)row[s + 1] <= cf) ++s;
+            while (s < max_value && (uint32_t)row[s + 1] <= cf) ++s;     // bounded: never reads past row[len-1]
         } else {
             int32_t lo = 0, hi = max_value + 1;
             while (hi - lo > 1) {

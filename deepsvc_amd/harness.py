@@ -37,13 +37,19 @@ def _msssim(a, b):
     return float(ms_ssim(a.contiguous(), b.contiguous(), 1.0))
 
 
-def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=None, msssim=False):
+def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=None, msssim=False, overlap_coding=False):
     """Encode+decode one GOP.  frames[1:] are P-frames; frames[0] is the key frame: taken as already decoded when
     `i_model` is None (BASELINE.json configs 1-2), else coded with the I-frame codec `i_model` (`ICIP2020ResB`,
     test_video.py:296-312: compress -> decompress, the clamped reconstruction becomes the first reference) and reported
     as a row with frame index 0 whose `bpp_res` column holds the I-frame bpp.  All frames are [1,3,h,w] tensors on the
     model's device, un-padded.  Returns one metric row per coded frame.  `msssim=True` fills the last column with MS-SSIM of
-    the cropped reconstruction (test_video.py:311,359-363; GPU kernel, frames must exceed 160 px on the smaller side)."""
+    the cropped reconstruction (test_video.py:311,359-363; GPU kernel, frames must exceed 160 px on the smaller side).
+
+    Timing: `DeepSVC.compress` returns while the host range coder is still writing the strings (PendingStrings).  By default
+    the encode clock `t_enc` stops only after both codings have been JOINED, so t_enc / t_dec mean what the reference's
+    timers mean (test_video.py:340-351: strings exist when compress returns).  `overlap_coding=True` is the throughput mode:
+    the strings are joined by whoever reads them first (the decoder), which overlaps the residual range coding with the
+    decoder's motion path -- t_enc then excludes, and t_dec includes, that coding time; t_enc + t_dec is the same either way."""
     sync = sync or (lambda: None)
     h, w = frames[0].shape[-2:]
     rows = []
@@ -65,6 +71,10 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
         sm = sm_feas[t]
         sync(); t0 = time.perf_counter()
         mv_enc, res_enc = model.compress(ref, cur, sm, feature)
+        if not overlap_coding:
+            for enc in (mv_enc, res_enc):
+                if hasattr(enc, "result"):
+                    enc.result()
         sync(); t1 = time.perf_counter()
         feature, recon, warped, predict = model.decompress(ref, mv_enc, res_enc, sm, feature)
         sync(); t2 = time.perf_counter()
@@ -79,7 +89,7 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
     return rows
 
 
-def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None):
+def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None, overlap_coding=True):
     """Throughput mode: code the independent GOPs `gops` = [(frames, sm_feas), ...] on len(models) concurrent LANES of one
     GPU.  A lane is one model instance (own weights, scan workspaces and HIP graphs), one stream and one host thread; GOP u
     goes to lane u % L.  One GOP alone leaves the GPU idle ~20 % of a frame while the host range-decodes each scan level
@@ -125,7 +135,7 @@ def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None):
                 for u in mine[ln]:
                     frames, sms = gops[u]
                     out[u] = code_gop(models[ln], frames, sms, unit=u, sync=streams[ln].synchronize, metrics=metrics,
-                                      i_model=None if i_models is None else i_models[ln])
+                                      i_model=None if i_models is None else i_models[ln], overlap_coding=overlap_coding)
                 streams[ln].synchronize()
         except BaseException as e:          # surfaced in the caller's thread
             errors.append(e)

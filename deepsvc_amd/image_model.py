@@ -11,6 +11,7 @@ API, attribute paths and bitstream format follow the reference; the execution do
   * the encoder derives y_hat/z_hat directly (`q + mu`) instead of entropy-decoding its own output
     (image_model.py:207, video_model.py:141) -- identical values, since every kernel involved is deterministic.
 """
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -36,11 +37,24 @@ class PendingStrings(dict):
     def __init__(self, future):
         super().__init__()
         self._future = future
+        self._lock = threading.Lock()
+        self._error = None
 
     def _join(self):
-        if self._future is not None:
-            fut, self._future = self._future, None
-            super().update(fut.result())
+        """Idempotent and thread-safe: the first caller waits for the coder and fills the dict; concurrent callers wait on the
+        lock and then see the filled dict; a coder exception is kept and re-raised on every later access."""
+        if self._future is not None or self._error is not None:
+            with self._lock:
+                if self._error is not None:
+                    raise self._error
+                if self._future is not None:
+                    try:
+                        super().update(self._future.result())
+                    except BaseException as e:
+                        self._error = e
+                        raise
+                    finally:
+                        self._future = None
         return self
 
     def result(self):
@@ -76,6 +90,9 @@ class PendingStrings(dict):
     def __eq__(self, other):
         return dict.__eq__(self._join(), other)
 
+    def copy(self):
+        return dict(self._join().items())
+
     __hash__ = None
 
 
@@ -107,6 +124,23 @@ class _ScanPlan:
         self.z_sym, self.z_sym_host = i32(self.nz, device=device), i32(self.nz, pin_memory=True)
         self.idx_dev, self.sym_dev = i32(gmax * self.ns, device=device), i32(gmax * self.ns, device=device)
         self.idx_host, self.sym_host = i32(gmax * self.ns, pin_memory=True), i32(gmax * self.ns, pin_memory=True)
+
+
+def rename_legacy_keys(state_dict):
+    """Key spellings of older checkpoints (reference utils.py:105-125 `rename_key`, applied by `load_pretrained`): a
+    DataParallel `module.` prefix and EntropyBottleneck parameters kept in nn.ParameterLists
+    (`entropy_bottleneck._matrices.N / _biases.N / _factors.N` -> `_matrixN / _biasN / _factorN`), at any nesting depth."""
+    out = {}
+    for k, v in state_dict.items():
+        if k.startswith("module."):
+            k = k[7:]
+        for old, new in (("entropy_bottleneck._matrices.", "entropy_bottleneck._matrix"),
+                         ("entropy_bottleneck._biases.", "entropy_bottleneck._bias"),
+                         ("entropy_bottleneck._factors.", "entropy_bottleneck._factor")):
+            if old in k:
+                k = k.replace(old, new)
+        out[k] = v
+    return out
 
 
 def conv3x3(cin, cout, stride=1):
@@ -507,7 +541,9 @@ class ChannelSplitICIP2020ResB(nn.Module):
         return {"x_hat": self.run_decompress(strings, shape, dev, x_hat_dtype=F32).nchw()}
 
     def load_state_dict(self, state_dict, strict=True):
-        """reference image_model.py:304-317: size the (initially empty) table buffers from the checkpoint first."""
+        """reference image_model.py:304-317: size the (initially empty) table buffers from the checkpoint first.
+        Older checkpoints' key spellings (utils.py:105-125 `rename_key`) are accepted as well."""
+        state_dict = rename_legacy_keys(state_dict)
         for mod, prefix, names in ((self.entropy_bottleneck, "entropy_bottleneck", ("_quantized_cdf", "_offset", "_cdf_length")),
                                    (self.gaussian_conditional, "gaussian_conditional",
                                     ("_quantized_cdf", "_offset", "_cdf_length", "scale_table"))):

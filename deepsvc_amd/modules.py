@@ -157,6 +157,16 @@ def bilinearupsacling(inputfeature):
     return ops.upsample2x(to_act(inputfeature)).nchw()
 
 
+def read_image(filepath):
+    """reference modules.py:65-68: image file -> float tensor [3,H,W] in [0,1] (PIL + ToTensor there; no torchvision here)."""
+    import os
+    assert os.path.isfile(filepath)
+    import numpy as np
+    from PIL import Image
+    img = np.asarray(Image.open(filepath).convert("RGB"), dtype=np.uint8)
+    return torch.from_numpy(img.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div_(255.0)
+
+
 def cal_psnr(a, b):
     """reference modules.py:71-73 (a, b: same-shape tensors in [0,1])."""
     mse = F.mse_loss(a, b).item()

@@ -5,9 +5,11 @@ The reference ships no checkpoints and PyTorch's default init leaves the entropy
 *calibrated* synthetic weights:
 
     W0 = default init of `DeepSVC()` under torch.manual_seed(0)   (CPU generator => same bits on every box)
-         x the per-tensor multipliers committed in deepsvc_amd/data/w0_calibration.json
-         (made by tools/calibrate_w0.py: flow of a few pixels, std(y) ~ 1, std(z) ~ 1, sigma spread over the table).
-    W1 = same recipe under seed 1 ("MS-SSIM" stand-in of BASELINE.json config 4).
+         x the per-tensor recipe committed in deepsvc_amd/data/w0_calibration.json
+         (made by tools/calibrate_w0.py: flow ~ true motion + ~1 px, std(y) ~ 1, std(z) ~ 1, sigma spread over the table,
+          prediction blended toward the warped frame, un-saturated reconstruction with a ridge-fitted last conv so that
+          the decoded frame approximates the current frame and the chain ref <- recon stays a picture).
+    W1 = same recipe under seed 1 (w1_calibration.json; "MS-SSIM" stand-in of BASELINE.json config 4).
 
 Frames: a smooth random texture translating (2,1) px/frame + N(0, 0.01^2) noise, seed 1234;
 semantic feature: relu(N(0,1)) [1,256,H/4,W/4], seed 1234+t.
@@ -20,6 +22,7 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CALIBRATION = os.path.join(HERE, "data", "w0_calibration.json")
+CALIBRATIONS = {"W0": CALIBRATION, "W1": os.path.join(HERE, "data", "w1_calibration.json")}
 ICIP_CALIBRATION = os.path.join(HERE, "data", "icip_w0_calibration.json")
 
 
@@ -49,10 +52,15 @@ def load_calibration(path=CALIBRATION):
 
 
 def apply_calibration(state_dict, calib):
-    """calib["tensors"]: key -> {"mul": m, "add": a}: tensor <- tensor * m + a (in place on a copy)."""
+    """calib["tensors"]: key -> {"mul": m, "add": a}: tensor <- tensor * m + a (a: scalar or one value per output channel),
+    or {"set": [...]}: the whole tensor (flattened).  Returns a modified copy."""
     out = {k: v.clone() for k, v in state_dict.items()}
     for key, spec in calib["tensors"].items():
-        out[key] = out[key] * float(spec.get("mul", 1.0)) + float(spec.get("add", 0.0))
+        if "set" in spec:
+            out[key] = torch.tensor(spec["set"], dtype=out[key].dtype).reshape(out[key].shape)
+            continue
+        add = torch.as_tensor(spec.get("add", 0.0), dtype=out[key].dtype)
+        out[key] = out[key] * float(spec.get("mul", 1.0)) + add
     return out
 
 
@@ -84,7 +92,7 @@ def make_model(weight_set="W0", calibrated=True, lam=2048):
     model = DeepSVC()
     torch.random.set_rng_state(rng)
     if calibrated:
-        sd = apply_rate_point(apply_calibration(model.state_dict(), load_calibration()), lam)
+        sd = apply_rate_point(apply_calibration(model.state_dict(), load_calibration(CALIBRATIONS[weight_set])), lam)
         with torch.no_grad():
             for k, v in model.state_dict().items():
                 v.copy_(sd[k])

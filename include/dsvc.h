@@ -236,7 +236,9 @@ typedef struct dsvc_cdf_table {
     int32_t rows, stride;
     const int32_t* cdf_length; /* [rows] */
     const int32_t* offset;     /* [rows] */
-    const uint16_t* lut;       /* optional [rows][256] decode accelerator from dsvc_cdf_build_lut, or NULL */
+    const uint16_t* lut;       /* optional [rows][256] decode accelerator: MUST come from dsvc_cdf_build_lut (which validates
+                                  every row: starts at 0, strictly increasing, ends at 65536), or NULL -- then the coder
+                                  validates the rows itself on every call */
 } dsvc_cdf_table;
 /* lut_out[row*256 + b] = largest symbol s with cdf[row][s] <= (b << 8): the decoder starts its search there */
 int dsvc_cdf_build_lut(const dsvc_cdf_table* t, uint16_t* lut_out);

@@ -246,11 +246,14 @@ class DeepSVCOracle:
     def decompress(self, ref, mv_enc, res_enc, sm_fea, feature, taps=None):
         r = self.root
         self.update()
-        mv1 = codec_decompress(r.sub("mv_codec"), self.tables["mv"], mv_enc["strings"], mv_enc["shape"])["x_hat"]
+        mv_t, res_t = ({}, {}) if taps is not None else (None, None)
+        mv1 = codec_decompress(r.sub("mv_codec"), self.tables["mv"], mv_enc["strings"], mv_enc["shape"], mv_t)["x_hat"]
         warped, warp_fea, predict = self._predict(ref, mv1, sm_fea, feature, taps)
         predict_fea = N.feature_extraction(r.sub("FeatureExtractor"), predict)
-        res1 = codec_decompress(r.sub("res_codec"), self.tables["res"], res_enc["strings"], res_enc["shape"])["x_hat"]
+        res1 = codec_decompress(r.sub("res_codec"), self.tables["res"], res_enc["strings"], res_enc["shape"], res_t)["x_hat"]
         feat, recon = self._reconstruct(ref, predict_fea, res1, warp_fea, taps)
+        if taps is not None:      # un-clamped tensors + decoded latents for the parity tests
+            taps.update(mv_y_hat=mv_t["y_hat"], res_y_hat=res_t["y_hat"], predict_fea=predict_fea)
         return feat, recon.clamp(0.0, 1.0), warped.clamp(0.0, 1.0), predict.clamp(0.0, 1.0)
 
 

@@ -117,6 +117,15 @@ def eb_forward(sd, prefix, z):
     return back(out), back(lik)
 
 
+def eb_loss(sd, prefix, tail_mass=1e-9):
+    """EntropyBottleneck.loss() (A.2; summed by video_model.py:169-177): sum |logits(quantiles) - (-t, 0, t)|,
+    t = log(2 / tail_mass - 1)."""
+    import math
+    t = math.log(2.0 / tail_mass - 1.0)
+    target = torch.tensor([-t, 0.0, t], dtype=torch.float32)
+    return torch.abs(eb_logits(sd, prefix, sd[f"{prefix}quantiles"]) - target).sum()
+
+
 def eb_tables(sd, prefix):
     """update(): integer CDF tables {cdf [C,L], cdf_length [C], offset [C]}."""
     q = sd[f"{prefix}quantiles"]

@@ -25,6 +25,12 @@ def golden128():
 
 
 @pytest.fixture(scope="session")
+def golden256():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "deepsvc_ref_256.npz"))
+
+
+@pytest.fixture(scope="session")
 def w0_state_dict():
     from deepsvc_amd import synth
     return synth.make_model("W0").state_dict()

@@ -1,5 +1,6 @@
 """Generate tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference) on the
-synthetic inputs / W0 weights of deepsvc_amd.synth.  Build-container only: /root/reference does not exist on
+synthetic inputs / W0 weights of deepsvc_amd.synth (64x64 first + steady-state P-frame with every stage tapped, 128x128
+steady-state, and a 256x256 septuplet = BASELINE.json config 1: six chained P-frames through compress()/decompress()).  Build-container only: /root/reference does not exist on
 the GPU box, where only the committed .npz files are used.
 
     python tests/golden/make_golden.py
@@ -166,11 +167,11 @@ def import_reference():
 # ------------------------------------------------------------------------------------------------
 # capture
 # ------------------------------------------------------------------------------------------------
-def compact(name, t, out):
+def compact(name, t, out, stride=4):
     a = t.detach().to(torch.float32).cpu().numpy()
     out[name + "/shape"] = np.asarray(a.shape, dtype=np.int64)
     out[name + "/stats"] = np.asarray([a.astype(np.float64).sum(), (a.astype(np.float64) ** 2).sum()])
-    out[name + "/data"] = a if a.size <= 16384 else a[..., ::4, ::4].copy()
+    out[name + "/data"] = a if a.size <= 16384 else a[..., ::stride, ::stride].copy()
 
 
 TAPPED = ["opticFlow", "mv_codec.g_a", "mv_codec.h_a", "mv_codec.h_mean_s", "mv_codec.h_scale_s", "mv_codec.g_s",
@@ -229,6 +230,32 @@ def run_case(ref_model, size, with_feature, out, tag):
         compact(f"{tag}/in/feature", feature, out)
 
 
+def run_septuplet(ref_model, size, out, tag, n_frames=7):
+    """BASELINE.json config 1: one size x size septuplet, frame 0 given as the decoded key frame, 6 chained P-frames through
+    the reference's compress()/decompress() (state chaining of test_video.py:342-369).  Per frame: the four byte strings,
+    the decoded pictures (sub-sampled + full-tensor sums), PSNR; decoded feature of the first and last frame."""
+    H = W = size
+    frames = synth.make_frames(H, W, n_frames)
+    ref_frame, feature = frames[0], None
+    psnrs = []
+    with torch.no_grad():
+        for t in range(1, n_frames):
+            sm = synth.make_sm_fea(H, W, t)
+            mv, res = ref_model.compress(ref_frame, frames[t], sm, feature)
+            feature, recon, warped, predict = ref_model.decompress(ref_frame, mv, res, sm, feature)
+            for nm, enc in (("mv", mv), ("res", res)):
+                out[f"{tag}/f{t}/enc/{nm}_y"] = np.frombuffer(enc["strings"][0][0], dtype=np.uint8)
+                out[f"{tag}/f{t}/enc/{nm}_z"] = np.frombuffer(enc["strings"][1][0], dtype=np.uint8)
+                out[f"{tag}/f{t}/enc/{nm}_shape"] = np.asarray(enc["shape"], dtype=np.int64)
+            for name, tns in (("recon", recon), ("warped", warped), ("predict", predict)):
+                compact(f"{tag}/f{t}/dec/{name}", tns, out)
+            if t in (1, n_frames - 1):
+                compact(f"{tag}/f{t}/dec/feature", feature, out, stride=8)
+            psnrs.append(-10.0 * float(torch.log10(((recon - frames[t]) ** 2).mean())))
+            ref_frame = recon
+    out[f"{tag}/psnr"] = np.asarray(psnrs, dtype=np.float64)
+
+
 def main():
     vm = import_reference()
     torch.manual_seed(0)
@@ -258,7 +285,10 @@ def main():
     keep = {k: v for k, v in out2.items() if "/enc/" in k or "/dec/" in k or k.endswith("scalars") or "out_" in k or "/in/" in k
             or "opticFlow" in k or "cc_" in k}
     np.savez_compressed(os.path.join(HERE, "deepsvc_ref_128.npz"), **keep)
-    for f in ("deepsvc_ref_64.npz", "deepsvc_ref_128.npz"):
+    out3 = {}
+    run_septuplet(ref_model, 256, out3, "s256_gop")
+    np.savez_compressed(os.path.join(HERE, "deepsvc_ref_256.npz"), **out3)
+    for f in ("deepsvc_ref_64.npz", "deepsvc_ref_128.npz", "deepsvc_ref_256.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
     # key/shape table of the whole state dict (checkpoint-compat contract for the product)
     with open(os.path.join(HERE, "state_dict_keys.txt"), "w") as f:

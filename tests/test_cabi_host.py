@@ -167,3 +167,25 @@ def test_weight_packing_layout(compute):
                     assert np.array_equal(arr[chunk, :, n, e], want)
             chunk += 1
         cbase += c
+
+
+def test_malformed_cdf_tables_are_rejected():
+    """CDF tables reach the coder from checkpoint buffers (entropy_models.host_tables): a row that does not start at 0, end at
+    65536 or has a zero-frequency symbol is refused when the table is built (dsvc_cdf_build_lut) instead of producing an
+    undecodable stream or an out-of-bounds read in the decoder."""
+    good = np.array([[0, 10, 40000, 65536, 0], [0, 1, 2, 3, 65536]], dtype=np.int32)
+    lens, offs = np.array([4, 5], dtype=np.int32), np.array([-1, -2], dtype=np.int32)
+    t = ops.CdfTables(good, lens, offs)
+    enc = ops.RansEncoder()
+    enc.encode_with_indexes(np.array([0, -1, 1, 5, -7], dtype=np.int32), np.array([0, 0, 1, 1, 0], dtype=np.int32), t)
+    data = enc.flush()
+    out = ops.RansDecoder(data).decode_stream(np.array([0, 0, 1, 1, 0], dtype=np.int32), t)
+    assert list(out) == [0, -1, 1, 5, -7]
+    for bad_row, why in (([1, 10, 40000, 65536, 0], "does not start at 0"), ([0, 10, 10, 65536, 0], "zero-frequency symbol"),
+                         ([0, 10, 40000, 65535, 0], "does not end at 65536"), ([0, 50000, 40000, 65536, 0], "not monotone")):
+        bad = good.copy()
+        bad[0] = bad_row
+        with pytest.raises(RuntimeError):
+            ops.CdfTables(bad, lens, offs)
+    with pytest.raises(RuntimeError):
+        ops.CdfTables(good, np.array([4, 6], dtype=np.int32), offs)        # cdf_length beyond the row stride

@@ -1,0 +1,118 @@
+"""The drop-in boundary exercised the way the reference's harness uses it (test_video.py): dropin/ ahead on sys.path, the
+harness's own import lines, then its model set-up (:230-236, :254-265) and per-frame call sequence (:293-305, :342, :349,
+:353-369) on a PNG-backed GOP -- I-frame codec for the key frame, two chained P-frames -- with a checkpoint written by
+torch.save and loaded through `load_state_dict(torch.load(...)["state_dict"])`.  Results are compared with coding the same
+frames through the package API directly (bit-identical) and with the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_harness_call_sequence_through_dropin(tmp_path, oracle_w0):
+    from deepsvc_amd import ops, synth
+    ops.set_precision("fp32")
+    # ---- checkpoints as the reference expects them on disk (weights = the synthetic W0 sets, tables sized by update()) ----
+    src_p = synth.make_model("W0"); src_p.update(force=True)
+    src_i = synth.make_icodec("W0"); src_i.update(force=True)
+    torch.save({"state_dict": src_p.state_dict()}, str(tmp_path / "p.pth"))
+    torch.save({"state_dict": src_i.state_dict()}, str(tmp_path / "i.pth"))
+    # ---- frames as PNG files (1080p-like aspect at test size: 120x200 -> padded 128x256) ----
+    from PIL import Image
+    H, W, n = 120, 200, 3
+    frames = synth.make_frames(128, 256, n)
+    paths = []
+    for t, f in enumerate(frames):
+        img = (f[0, :, 4:4 + H, 28:28 + W].permute(1, 2, 0) * 255).round().clamp(0, 255).to(torch.uint8).numpy()
+        paths.append(str(tmp_path / f"im{t + 1:05d}.png"))
+        Image.fromarray(img).save(paths[-1])
+
+    saved_path, saved_mods = list(sys.path), {k: sys.modules.get(k) for k in ("video_model", "image_model", "modules")}
+    sys.path.insert(0, os.path.join(ROOT, "dropin"))
+    try:
+        for k in saved_mods:
+            sys.modules.pop(k, None)
+        # test_video.py:8,10,11 verbatim
+        from image_model import ICIP2020ResB
+        from video_model import DeepSVC
+        from modules import read_image, cal_psnr, crop, pad
+        device = "cuda:0"                                                     # test_video.py:198
+        p_model = DeepSVC()                                                   # :230-236
+        pcheckpoint = torch.load(str(tmp_path / "p.pth"), map_location="cpu")
+        p_model.load_state_dict(pcheckpoint["state_dict"])
+        p_model.eval()
+        p_model.update(force=True)
+        p_model.to(device)
+        i_model = ICIP2020ResB()                                              # :254-265
+        icheckpoint = torch.load(str(tmp_path / "i.pth"), map_location="cpu")
+        i_model.load_state_dict(icheckpoint["state_dict"])
+        i_model.update(force=True)
+        i_model.to(device)
+        i_model.eval()
+
+        image = read_image(paths[0]).unsqueeze(0)                             # :287-288
+        _, _, org_h, org_w = image.size()
+        assert (org_h, org_w) == (H, W)
+        feature, rows = None, []
+        for i, im in enumerate(paths):                                        # :290-369
+            curr_frame_org = read_image(im).unsqueeze(0).to(device)
+            curr_frame = pad(curr_frame_org, 64)
+            num_pixels = curr_frame_org.size(0) * curr_frame_org.size(2) * curr_frame_org.size(3)
+            if i == 0:
+                feature = None
+                i_out_enc = i_model.compress(curr_frame)
+                torch.cuda.synchronize()
+                i_out_dec = i_model.decompress(i_out_enc["strings"], i_out_enc["shape"])
+                torch.cuda.synchronize()
+                i_bpp = sum(len(s[0]) for s in i_out_enc["strings"]) * 8.0 / num_pixels
+                i_psnr = cal_psnr(curr_frame_org, crop(i_out_dec["x_hat"], (org_h, org_w)))
+                rows.append(("I", i_bpp, i_psnr))
+                ref_frame = i_out_dec["x_hat"]
+                key_ref = ref_frame.clone()
+            else:
+                sm0 = synth.make_sm_fea(128, 256, i).to(device)               # stands in for sm_p(...)[0][0:1] (:336, out of scope)
+                torch.cuda.synchronize()
+                mv_out_enc, res_out_enc = p_model.compress(ref_frame, curr_frame, sm0, feature)
+                torch.cuda.synchronize()
+                feature1, dec_p_frame, warped_frame, predict_frame = \
+                    p_model.decompress(ref_frame, mv_out_enc, res_out_enc, sm0, feature)
+                torch.cuda.synchronize()
+                mse = torch.mean((curr_frame_org - crop(dec_p_frame, (org_h, org_w))).pow(2)).item()
+                p_psnr = 10 * np.log10(1.0 / mse).item()
+                res_bpp = sum(len(s[0]) for s in res_out_enc["strings"]) * 8.0 / num_pixels
+                mv_bpp = sum(len(s[0]) for s in mv_out_enc["strings"]) * 8.0 / num_pixels
+                rows.append(("P", mv_bpp + res_bpp, p_psnr, mv_out_enc, res_out_enc, dec_p_frame.clone(), feature1.float().clone()))
+                ref_frame = dec_p_frame.detach()
+                feature = feature1.detach()
+    finally:
+        sys.path[:] = saved_path
+        for k, v in saved_mods.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+
+    assert rows[0][1] > 0 and np.isfinite(rows[0][2]) and rows[0][2] > 10
+    assert all(r[1] > 0 and np.isfinite(r[2]) and r[2] > 15 for r in rows[1:]), [r[:3] for r in rows]
+
+    # ---- the same P-frames on the CPU oracle (same weights, same decoded key frame, same padded frames): identical bytes,
+    #      decoded frame / feature within the fp32 parity bounds ----
+    import parity_util as PU
+    from oracle.nets import pad64
+    ref_o, feat_o = key_ref.cpu(), None
+    for i in (1, 2):
+        from deepsvc_amd.modules import read_image as ri
+        cur = pad64(ri(paths[i]).unsqueeze(0))
+        sm0 = synth.make_sm_fea(128, 256, i)
+        mv_o, res_o = oracle_w0.compress(ref_o, cur, sm0, feat_o)
+        feat_o, ref_o, _, _ = oracle_w0.decompress(ref_o, mv_o, res_o, sm0, feat_o)
+        _, _, _, mv_g, res_g, dec_g, feat_g = rows[i]
+        for eg, eo in ((mv_g, mv_o), (res_g, res_o)):
+            assert eg["strings"][0][0] == eo["strings"][0][0] and eg["strings"][1][0] == eo["strings"][1][0], f"frame {i}: bytes differ from the oracle's"
+        e_r, e_f = PU.rel_l2(dec_g.cpu(), ref_o), PU.rel_l2(feat_g.cpu(), feat_o)
+        print(f"[dropin] frame {i}: recon rel-L2 {e_r:.2e}, feature rel-L2 {e_f:.2e}, bpp {rows[i][1]:.3f}, PSNR {rows[i][2]:.2f} dB")
+        assert e_r <= PU.FP32_BOUNDS["recon"] and e_f <= PU.FP32_BOUNDS["feature"]

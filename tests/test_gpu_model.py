@@ -1,10 +1,10 @@
-"""GPU parity of the module layer and of whole P-frames: the HIP path (through the C ABI) against the CPU oracle
-on the same seeded inputs / W0 weights, and against the golden vectors captured from the reference itself.
+"""GPU parity of the module layer (stage by stage) and full-size properties: the HIP path (through the C ABI) against the
+CPU oracle on the same seeded inputs / W0 weights, and against the golden vectors captured from the reference itself.
+Whole-frame parity of the bitstream path (bytes, symbols, un-clamped decoded tensors, the reference's golden strings,
+mutation test) lives in tests/test_gpu_parity.py.
 
-Tolerances (fp32 mode): intermediate tensors 1e-3 of the tensor's max (deep fp32 conv chains with different
-summation order); frames 2e-3 absolute.  Cross-device bit equality of rounded symbols is not attainable
-(SURVEY section 7.2), so bitstream-level parity is stated as: symbol mismatch fraction <= 0.5 %, |d bpp| <= 1 %,
-|d PSNR| <= 0.05 dB -- the tolerances of BASELINE.json's north_star."""
+Tolerances (fp32 mode): intermediate tensors 1e-3 of the tensor's max per element (deep fp32 conv chains with different
+summation order) for the stage tests; relative L2 <= 5e-5 for the frame-level tensors (tests/parity_util.py)."""
 import numpy as np
 import pytest
 import torch
@@ -102,96 +102,37 @@ def test_forward_matches_oracle_and_reference_golden(model, oracle_w0, golden64,
     got = model(ref.to(DEV), cur.to(DEV), sm.to(DEV), None if feat is None else feat.to(DEV))
     want = oracle_w0.forward(ref, cur, sm, feat)
     gold = golden64[f"{tag}/fwd/scalars"]            # produced by the reference itself
-    recon, recon_w = got[0].cpu(), want[0]
-    assert psnr(recon, recon_w) > 45, f"recon PSNR vs oracle {psnr(recon, recon_w):.1f} dB"
+    import parity_util as PU
+    # un-clamped reconstruction and the decoded feature: vs the oracle and vs the reference's golden tensors
+    for j, name in ((0, "recon"), (1, "feature")):
+        e = PU.rel_l2(got[j].float().cpu(), want[j])
+        print(f"{tag} forward {name}: rel-L2 vs oracle {e:.2e}")
+        assert e <= 1e-4, f"forward {name}: rel-L2 {e:.3e} vs oracle"
+        PU.check_golden(golden64, f"{tag}/fwd/out_{name}", got[j], rel=1e-4)
     g = [float(v) for v in got[2:]]
     w = [float(v) for v in want[2:]]
     print(tag, "gpu scalars", g, "oracle", w, "reference", list(gold))
     names = ["mse", "warp_mse", "mc_mse", "bpp_res", "bpp_mv", "bpp"]
     for n, a, b, c in zip(names, g, w, gold):
-        tol = 0.01 if n.startswith("bpp") else 0.02
+        # likelihood sums move when a latent sits on a rounding boundary: 1 % (north_star); the distortions are tight
+        tol = 0.01 if n.startswith("bpp") else 1e-3
         assert abs(a - b) <= tol * abs(b), f"{n}: gpu {a} vs oracle {b}"
         assert abs(a - c) <= tol * abs(c), f"{n}: gpu {a} vs reference golden {c}"
-    # PSNR delta of the reconstruction against the current frame, GPU vs reference
     d_psnr = abs(-10 * np.log10(g[0]) + 10 * np.log10(gold[0]))
-    assert d_psnr <= 0.05, f"|dPSNR| = {d_psnr:.4f} dB"
+    assert d_psnr <= 0.005, f"|dPSNR| = {d_psnr:.4f} dB"
 
 
-@pytest.mark.parametrize("size", [64, 128])
-def test_compress_decompress_roundtrip_and_parity(model, oracle_w0, size):
+def test_forward1_matches_oracle(model, oracle_w0):
+    """forward1 (video_model.py:73-94) -> (predict, warp_mse, mc_mse, bpp_mv): the motion half of the estimate path."""
+    import parity_util as PU
     from deepsvc_amd import synth
-    from oracle.codec import strings_nbytes
-    fr = synth.make_frames(size, size, 3)
-    ref_g, ref_o, feat_g, feat_o = fr[0].to(DEV), fr[0], None, None
-    for t in (1, 2):                       # two chained P-frames: first (feature=None) and steady-state
-        sm = synth.make_sm_fea(size, size, t)
-        cur = fr[t]
-        mv_g, res_g = model.compress(ref_g, cur.to(DEV), sm.to(DEV), feat_g)
-        dec_g = model.decompress(ref_g, mv_g, res_g, sm.to(DEV), feat_g)
-        mv_o, res_o = oracle_w0.compress(ref_o, cur, sm, feat_o)
-        dec_o = oracle_w0.decompress(ref_o, mv_o, res_o, sm, feat_o)
-        for enc in (mv_g, res_g):
-            assert isinstance(enc["strings"][0][0], bytes) and isinstance(enc["strings"][1][0], bytes)
-            assert tuple(enc["shape"]) == (size // 64, size // 64)
-        bytes_g = strings_nbytes(mv_g) + strings_nbytes(res_g)
-        bytes_o = strings_nbytes(mv_o) + strings_nbytes(res_o)
-        print(f"size {size} frame {t}: bytes gpu {bytes_g} oracle {bytes_o}; "
-              f"mv y equal {mv_g['strings'][0][0] == mv_o['strings'][0][0]}, res y equal {res_g['strings'][0][0] == res_o['strings'][0][0]}")
-        assert abs(bytes_g - bytes_o) <= max(0.01 * bytes_o, 8), "bpp differs by more than 1 %"
-        recon_g, recon_o = dec_g[1].cpu(), dec_o[1]
-        p_g, p_o = psnr(recon_g, cur), psnr(recon_o, cur)
-        print(f"   PSNR(recon,cur): gpu {p_g:.4f} oracle {p_o:.4f}; PSNR(gpu,oracle) {psnr(recon_g, recon_o):.1f} dB")
-        assert abs(p_g - p_o) <= 0.05, "PSNR delta above 0.05 dB"
-        assert psnr(recon_g, recon_o) > 40
-        assert float(recon_g.min()) >= 0 and float(recon_g.max()) <= 1
-        # decoder reproduces the encoder's prediction path exactly (deterministic kernels): decoding twice is bit-stable
-        dec_g2 = model.decompress(ref_g, mv_g, res_g, sm.to(DEV), feat_g)
-        assert torch.equal(dec_g2[1], dec_g[1]) and torch.equal(dec_g2[0], dec_g[0])
-        # estimate path and real path agree on the reconstruction (they differ only by ste_round's float path)
-        fwd = model(ref_g, cur.to(DEV), sm.to(DEV), feat_g)
-        assert psnr(fwd[0].clamp(0, 1).cpu(), recon_g) > 60
-        ref_g, feat_g = dec_g[1], dec_g[0]
-        ref_o, feat_o = dec_o[1], dec_o[0]
-
-
-def test_golden_bitstream_decodes_on_gpu_when_indexes_agree(model, golden64, oracle_w0):
-    """The reference's own y/z strings (golden) fed to the GPU decoder.  Index agreement between the GPU scan and
-    the CPU scan that produced the stream is not guaranteed bit-for-bit, so this test asserts the weaker, exact
-    property on the z-stream (no data-dependent indexes) and reports the y outcome."""
-    g = golden64
-    shape = tuple(int(v) for v in g["s64_first/enc/mv_shape"])
-    z_bytes = g["s64_first/enc/mv_z"].tobytes()
-    z_hat = model.mv_codec.entropy_bottleneck.decompress([z_bytes], shape).cpu()
-    from oracle import entropy as E
-    sd, pre = oracle_w0.sd, "mv_codec.entropy_bottleneck."
-    want = E.eb_decompress(sd, pre, oracle_w0.tables["mv"]["eb"], [z_bytes], shape)
-    assert torch.equal(z_hat, want)
-
-
-def test_bf16_mode_end_to_end(model, oracle_w0):
-    """Fast mode (bf16 MFMA, bf16 activation storage): same API, round trip still exact between encoder and
-    decoder; quality/rate deltas against the fp32 oracle are reported and bounded."""
-    from deepsvc_amd import ops, synth
-    from oracle.codec import strings_nbytes
-    size = 128
-    fr = synth.make_frames(size, size, 2)
-    sm = synth.make_sm_fea(size, size, 1)
-    mv_o, res_o = oracle_w0.compress(fr[0], fr[1], sm, None)
-    dec_o = oracle_w0.decompress(fr[0], mv_o, res_o, sm, None)
-    ops.set_precision("bf16")
-    try:
-        mv_g, res_g = model.compress(fr[0].to(DEV), fr[1].to(DEV), sm.to(DEV), None)
-        dec_g = model.decompress(fr[0].to(DEV), mv_g, res_g, sm.to(DEV), None)
-        dec_g2 = model.decompress(fr[0].to(DEV), mv_g, res_g, sm.to(DEV), None)
-    finally:
-        ops.set_precision("fp32")
-    assert torch.equal(dec_g[1], dec_g2[1])
-    b_g, b_o = strings_nbytes(mv_g) + strings_nbytes(res_g), strings_nbytes(mv_o) + strings_nbytes(res_o)
-    p_g, p_o = psnr(dec_g[1].cpu(), fr[1]), psnr(dec_o[1], fr[1])
-    print(f"bf16: bytes {b_g} vs {b_o} ({100 * (b_g - b_o) / b_o:+.2f} %), PSNR {p_g:.4f} vs {p_o:.4f} dB, "
-          f"PSNR(gpu,oracle) {psnr(dec_g[1].cpu(), dec_o[1]):.1f} dB")
-    assert abs(b_g - b_o) <= 0.03 * b_o
-    assert abs(p_g - p_o) <= 0.1
+    fr, sm = synth.make_frames(64, 64, 2), synth.make_sm_fea(64, 64, 1)
+    got = model.forward1(fr[0].to(DEV), fr[1].to(DEV), sm.to(DEV), None)
+    taps = {}
+    want = oracle_w0.forward(fr[0], fr[1], sm, None, taps)
+    assert PU.rel_l2(got[0].cpu(), taps["predict"]) <= 1e-4
+    for a, b, n in zip(got[1:], (want[3], want[4], want[6]), ("warp_mse", "mc_mse", "bpp_mv")):
+        assert abs(float(a) - float(b)) <= (0.01 if n == "bpp_mv" else 1e-3) * abs(float(b)), f"{n}: {float(a)} vs {float(b)}"
 
 
 def test_full_size_1080p_roundtrip_properties(oracle_w0):
@@ -200,8 +141,10 @@ def test_full_size_1080p_roundtrip_properties(oracle_w0):
       * encode -> decode round trip: the decoder's latents y_hat (both codecs) are bit-identical to the encoder's;
       * determinism / idempotence: decoding the same strings twice gives bit-identical frames and features;
       * a second, chained P-frame (feature and reference from the decoder) behaves the same;
-      * bf16 mode stays inside the north-star tolerance of fp32 mode on the same inputs: |d bytes| <= 1 %, and the two
-        reconstructions agree to > 40 dB."""
+      * bf16 mode stays inside the north-star tolerance of fp32 mode on the same inputs: |d bytes| <= 1 %, |d PSNR| <= 0.05 dB,
+        and the UN-CLAMPED reconstruction and the decoded 64-channel feature of bf16 mode are within the stated relative L2
+        of fp32 mode's (tests/parity_util.BF16_BOUNDS) -- the decoded frames are real pictures (< 1 % of pixels clamp), so
+        these numbers measure bf16, not the clamp."""
     from deepsvc_amd import ops, synth
     from deepsvc_amd.modules import pad
 
@@ -219,7 +162,10 @@ def test_full_size_1080p_roundtrip_properties(oracle_w0):
                 mv, res = {k: mv[k] for k in ("strings", "shape")}, {k: res[k] for k in ("strings", "shape")}   # joins the coders
                 torch.cuda.synchronize()
                 enc_lat = [c._plan(1, 68, 120, torch.device(DEV)).y_hat.buf.clone() for c in (model.mv_codec, model.res_codec)]
+                model.debug_taps = {}
                 f1, r1, w1, p1 = model.decompress(ref, mv, res, sms[t], feat)
+                raw = model.debug_taps["recon"].float().cpu()
+                model.debug_taps = None
                 torch.cuda.synchronize()
                 dec_lat = [c._plan(1, 68, 120, torch.device(DEV)).y_hat.buf.clone() for c in (model.mv_codec, model.res_codec)]
                 f2, r2, w2, p2 = model.decompress(ref, mv, res, sms[t], feat)
@@ -231,19 +177,24 @@ def test_full_size_1080p_roundtrip_properties(oracle_w0):
                 nbytes = sum(len(s[0]) for s in mv["strings"]) + sum(len(s[0]) for s in res["strings"])
                 assert nbytes > 1000 and tuple(mv["shape"]) == (17, 30)
                 assert torch.isfinite(r1).all() and float(r1.min()) >= 0.0 and float(r1.max()) <= 1.0
-                out.append((nbytes, r1.float().cpu()))
+                clamped = float(((raw < 0) | (raw > 1)).float().mean())
+                assert clamped < 0.01, f"{clamped:.3f} of the decoded pixels clamp: the weight set is degenerate at this size"
+                out.append((nbytes, raw, f1.float().cpu(), float(-10 * torch.log10(((r1 - frames[t]) ** 2).mean()))))
                 ref, feat = r1, f1
             return out
         finally:
             ops.set_precision("fp32")
 
+    import parity_util as PU
     a, b = run("fp32"), run("bf16")
-    for t, ((na, ra), (nb, rb)) in enumerate(zip(a, b), 1):
+    for t, ((na, ra, fa, pa), (nb, rb, fb, pb)) in enumerate(zip(a, b), 1):
+        e_rec, e_fea = PU.rel_l2(rb, ra), PU.rel_l2(fb, fa)
+        print(f"1080p frame {t}: fp32 {na} B / {pa:.3f} dB, bf16 {nb} B / {pb:.3f} dB ({100.0 * (nb - na) / na:+.3f} %, {pb - pa:+.4f} dB); "
+              f"bf16 vs fp32 rel-L2: un-clamped recon {e_rec:.2e}, feature {e_fea:.2e}; PSNR(bf16 recon, fp32 recon) {PU.psnr(rb, ra):.1f} dB")
         assert abs(nb - na) <= 0.01 * na, f"frame {t}: bf16 {nb} B vs fp32 {na} B"
-        mse = float(((ra - rb) ** 2).mean())
-        psnr = 99.0 if mse == 0 else -10.0 * float(np.log10(mse))
-        print(f"1080p frame {t}: fp32 {na} B, bf16 {nb} B ({100.0 * (nb - na) / na:+.3f} %), PSNR(bf16 recon, fp32 recon) = {psnr:.1f} dB")
-        assert psnr > 40.0
+        assert abs(pb - pa) <= 0.05, f"frame {t}: PSNR bf16 {pb:.4f} vs fp32 {pa:.4f} dB"
+        assert e_rec <= PU.BF16_BOUNDS["recon"] and e_fea <= PU.BF16_BOUNDS["feature"]
+        assert pa > 15.0
 
 
 def test_frame_container_round_trip_on_gpu(model):
@@ -262,32 +213,6 @@ def test_frame_container_round_trip_on_gpu(model):
     a = model.decompress(fr[0].to(DEV), mv, res, sm, None)
     b = model.decompress(fr[0].to(DEV), mv2, res2, sm, None)
     assert torch.equal(a[1], b[1]) and torch.equal(a[0].float(), b[0].float())
-
-
-def test_w1_weight_set_parity(oracle_w0):
-    """BASELINE.json config 4's "MS-SSIM model" is the same code path with another weight set: W1 (seed 1) through the
-    real bitstream path in fp32 mode against the oracle on the same weights -- bytes within 1 %, PSNR within 0.05 dB."""
-    from deepsvc_amd import ops, synth
-    from oracle.codec import DeepSVCOracle, strings_nbytes
-    ops.set_precision("fp32")
-    m = synth.make_model("W1")
-    m.update(force=True)
-    orc = DeepSVCOracle(m.state_dict())
-    orc.update(force=True)
-    m = m.to(DEV)
-    size = 64
-    fr = synth.make_frames(size, size, 2)
-    sm = synth.make_sm_fea(size, size, 1)
-    mv_g, res_g = m.compress(fr[0].to(DEV), fr[1].to(DEV), sm.to(DEV), None)
-    dec_g = m.decompress(fr[0].to(DEV), mv_g, res_g, sm.to(DEV), None)
-    mv_o, res_o = orc.compress(fr[0], fr[1], sm, None)
-    dec_o = orc.decompress(fr[0], mv_o, res_o, sm, None)
-    bg, bo = strings_nbytes(mv_g) + strings_nbytes(res_g), strings_nbytes(mv_o) + strings_nbytes(res_o)
-    print(f"W1 64x64: bytes gpu {bg} oracle {bo}; identical y strings: mv {mv_g['strings'][0][0] == mv_o['strings'][0][0]}, "
-          f"res {res_g['strings'][0][0] == res_o['strings'][0][0]}")
-    assert abs(bg - bo) <= max(0.01 * bo, 8)
-    assert abs(psnr(dec_g[1].cpu(), fr[1]) - psnr(dec_o[1], fr[1])) <= 0.05
-    assert psnr(dec_g[1].cpu(), dec_o[1]) > 40
 
 
 def test_4k_whole_frame_round_trip_bf16():

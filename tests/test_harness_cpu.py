@@ -105,3 +105,16 @@ def test_two_rank_gather_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+def test_bench_launcher_refuses_inconsistent_rank_counts():
+    """`bench.py --gpus N` launches its own ranks; it must fail loudly -- not silently measure one GPU -- when N GPUs are
+    not visible (no rehearsal flag) and when it is started under a launcher whose WORLD_SIZE differs from --gpus."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSVC_BENCH_REHEARSAL")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "visible" in r.stderr, r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "1"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr, r.stderr

@@ -1,16 +1,23 @@
-"""Make deepsvc_amd/data/w0_calibration.json: per-tensor multipliers that turn seeded default-init
-weights into a weight set that exercises the whole P-frame path.
+"""Make deepsvc_amd/data/{w0,w1}_calibration.json: the recipe that turns seeded default-init weights into a weight set
+that exercises the whole P-frame path with *non-degenerate* outputs at every stage.
 
 Runs on the CPU through the oracle (test infrastructure); the product only consumes the JSON.
-Targets (measured on synthetic frames 0->1 at 128x128):
-  * SpyNet: each level's residual flow has std ~1 px                    (opticFlow.moduleBasic.L.conv5)
-  * codecs: std(y) ~ 1, std(z) ~ 1                                         (g_a.12, h_a.6)
-            per slice std(mu) ~ 0.5, sigma ~ 0.6 + 0.35*N(0,1)           (cc_mean.i.6, cc_scale.i.6)
-            => ~1 bit per pixel: the order of magnitude of a high-rate P-frame, symbols mostly in -3..3,
-               sigma spread over ~20 of the 64 table levels, occasional escape-coded outliers
-            std(x_hat): 1.5 px for the mv codec, 0.05 for the residual codec (g_s.12)
+Per-tensor entries: tensor <- tensor * mul + add (add: scalar or one value per output channel), or "set": the whole
+tensor (used for one 3x3 conv, `enhance.recon_conv3`, fitted by ridge regression; 3 459 numbers).
 
-    python tools/calibrate_w0.py
+Targets (measured on synthetic frames at 128x128; chain of three P-frames):
+  * SpyNet: each level's residual flow is zero-mean with std 0.10/0.15/0.20/0.30 px (coarse -> fine); the coarsest
+    level's bias carries the synthetic sequence's true motion (2,1)/8 px  => flow ~ (2,1) + ~1 px of smooth noise
+  * codecs: std(y) ~ 1, std(z) ~ 1; per slice std(mu) ~ 0.5, sigma ~ 0.6 + 0.35*N(0,1)
+            => ~1 bit per pixel, symbols mostly in -3..3, sigma spread over ~20 of the 64 table levels, escapes occur
+            x_hat of the mv codec: (2,1) px + 0.5 px std;  x_hat of the residual codec: std 0.05
+  * MC:     blend weight w = sigmoid(N(2, 0.5^2)) ~ 0.88 toward `warped`; out_conv(up_out) ~ 0.5 +- 0.15
+  * enhance (round-2 fix: the round-1 set decoded a 90 %-black frame, which made every frame-level parity check vacuous):
+            blend weights w1, w2 = sigmoid(N(-2, 0.5^2)) ~ 0.12 each, recon_conv1/2 ~ 0.5 +- 0.10, and recon_conv3
+            (weight 1-w1-w2 ~ 0.76) ridge-fitted so that the decoded frame approximates the current frame
+            => < 1 % of the decoded pixels clamp, PSNR(recon, cur) ~ 20 dB, the chain ref <- recon stays a picture.
+
+    python tools/calibrate_w0.py            # writes both files
 """
 import json
 import os
@@ -28,6 +35,9 @@ from oracle import entropy as E  # noqa: E402
 from oracle import nets as N  # noqa: E402
 from oracle.nets import P  # noqa: E402
 
+FLOW_STD = [0.10, 0.15, 0.20, 0.30]
+TRUE_MOTION = (2.0, 1.0)          # synth.make_frames translates (2,1) px per frame
+
 
 class Calib:
     def __init__(self, sd):
@@ -35,24 +45,50 @@ class Calib:
         self.spec = {}
 
     def scale(self, key, mul, add=0.0):
-        self.sd[key] = self.sd[key] * mul + add
+        """tensor <- tensor*mul + add; add may be a per-output-channel list (1-D tensors only)."""
+        add_t = torch.as_tensor(add, dtype=torch.float32)
+        self.sd[key] = self.sd[key] * mul + add_t
         cur = self.spec.get(key, {"mul": 1.0, "add": 0.0})
-        self.spec[key] = {"mul": cur["mul"] * mul, "add": cur["add"] * mul + add}
+        prev = torch.as_tensor(cur["add"], dtype=torch.float32)
+        new_add = prev * mul + add_t
+        self.spec[key] = {"mul": cur["mul"] * mul, "add": new_add.tolist() if new_add.dim() else float(new_add)}
+
+    def set(self, key, value):
+        self.sd[key] = value.to(torch.float32).clone()
+        self.spec[key] = {"set": value.to(torch.float32).flatten().tolist()}
 
     def scale_conv(self, prefix, mul, bias_add=0.0):
         self.scale(prefix + "weight", mul)
         self.scale(prefix + "bias", mul, bias_add)
 
+    def normalise(self, prefix, fn, std, mean):
+        """Scale the conv at `prefix` (weight+bias) so fn() has the given std, then shift its bias per output channel so
+        every channel of fn() has the given mean.  fn() must be affine in that conv's output."""
+        out = fn()
+        self.scale_conv(prefix, std / float(out.std().clamp_min(1e-8)))
+        out = fn()
+        shift = torch.as_tensor(mean, dtype=torch.float32) - out.mean(dim=(0, 2, 3))
+        self.scale(prefix + "bias", 1.0, shift.tolist())
+        return fn()
+
+
+def _weight_logit(p, x):
+    """pre-sigmoid output of a `weight` head (modules.py:329-341, 412-417)."""
+    o = N.conv(p.sub("0"), x)
+    o = N.res_block1(p.sub("1"), o)
+    return N.conv(p.sub("2"), o)
+
 
 @torch.no_grad()
-def calibrate(seed_set="W0", size=128):
+def calibrate(seed_set="W0", size=128, verbose=True):
     model = synth.make_model(seed_set, calibrated=False)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     cal = Calib(sd)
     root = P(sd)
-    frames = synth.make_frames(size, size, 2)
+    frames = synth.make_frames(size, size, 4)
     ref, cur = frames[0], frames[1]
     sm = synth.make_sm_fea(size, size, 1)
+    say = print if verbose else (lambda *a, **k: None)
 
     # ---- SpyNet, level by level ----
     L = 4
@@ -66,14 +102,13 @@ def calibrate(seed_set="W0", size=128):
         up = N.upsample2x(flow) * 2.0
         k = L - 1 - lvl
         x = torch.cat([pyr1[k], N.warp(pyr2[k], up), up], 1)
-        r = N.me_basic(p.sub(f"moduleBasic.{lvl}"), x)
-        g = 1.0 / float(r.std().clamp_min(1e-8))
-        cal.scale_conv(f"opticFlow.moduleBasic.{lvl}.conv5.", g)
-        flow = up + N.me_basic(p.sub(f"moduleBasic.{lvl}"), x)
+        mean = [m / 8.0 for m in TRUE_MOTION] if lvl == 0 else [0.0, 0.0]
+        r = cal.normalise(f"opticFlow.moduleBasic.{lvl}.conv5.", lambda: N.me_basic(p.sub(f"moduleBasic.{lvl}"), x), FLOW_STD[lvl], mean)
+        flow = up + r
     mv_est = flow
-    print(f"flow std {float(flow.std()):.3f} max {float(flow.abs().max()):.3f}")
+    say(f"flow mean {flow.mean(dim=(0, 2, 3)).tolist()} std {float(flow.std()):.3f} max {float(flow.abs().max()):.3f}")
 
-    def calibrate_codec(name, x, xhat_std):
+    def calibrate_codec(name, x, xhat_std, xhat_mean):
         q = root.sub(name)
         y = C.g_a(q, x)
         cal.scale_conv(f"{name}.g_a.12.", 1.0 / float(y.std()))
@@ -99,27 +134,92 @@ def calibrate(seed_set="W0", size=128):
             y_hat = torch.round(y_slice - mu) + mu
             y_hat_slices.append(C._lrp(q, i, ms, y_hat))
         y_hat = torch.cat(y_hat_slices, 1)
-        x_hat = C.g_s(q, y_hat)
-        cal.scale_conv(f"{name}.g_s.12.", xhat_std / float(x_hat.std()))
-        x_hat = C.g_s(q, y_hat)
-        print(f"{name}: std(y)={float(y.std()):.2f} std(z)={float(z.std()):.2f} std(x_hat)={float(x_hat.std()):.3f}")
+        x_hat = cal.normalise(f"{name}.g_s.12.", lambda: C.g_s(q, y_hat), xhat_std, xhat_mean)
+        say(f"{name}: std(y)={float(y.std()):.2f} std(z)={float(z.std()):.2f} std(x_hat)={float(x_hat.std()):.3f}")
         return x_hat
 
-    mv1 = calibrate_codec("mv_codec", torch.cat([cur, mv_est, ref], 1), 1.5)
+    mv1 = calibrate_codec("mv_codec", torch.cat([cur, mv_est, ref], 1), 0.5, list(TRUE_MOTION))
     mv = N.refine_net(root.sub("RefineMvNet"), mv1, ref)
     warped = N.warp(ref, mv)
-    _, predict = N.inter_layer_prediction(root.sub("MC"), ref, warped, mv, sm, None)
-    pf = N.feature_extraction(root.sub("FeatureExtractor"), predict)
-    cf = N.feature_extraction(root.sub("FeatureExtractor"), cur)
-    calibrate_codec("res_codec", torch.cat([ref, cf - pf, predict], 1), 0.05)
+
+    # ---- MC heads: predict = w*warped + (1-w)*out_conv(up_out), w ~ 0.88 ----
+    mc = root.sub("MC")
+    up_out, _ = N.inter_layer_prediction(mc, ref, warped, mv, sm, None)
+    cal.normalise("MC.weight.2.", lambda: _weight_logit(mc.sub("weight"), up_out), 0.5, 2.0)
+    cal.normalise("MC.out_conv.", lambda: N.conv(mc.sub("out_conv"), up_out), 0.15, 0.5)
+    up_out, predict = N.inter_layer_prediction(mc, ref, warped, mv, sm, None)
+    psnr = lambda a, b: -10.0 * float(torch.log10(((a - b) ** 2).mean()))
+    say(f"PSNR(warped,cur) {psnr(warped, cur):.2f}  PSNR(predict,cur) {psnr(predict, cur):.2f}")
+
+    fe = root.sub("FeatureExtractor")
+    pf = N.feature_extraction(fe, predict)
+    cf = N.feature_extraction(fe, cur)
+    res1 = calibrate_codec("res_codec", torch.cat([ref, cf - pf, predict], 1), 0.05, [0.0] * 64)
+
+    # ---- enhance: unsaturated heads + ridge-fitted recon_conv3 ----
+    en = root.sub("enhance")
+
+    def enhance_parts(ref_, pf_, res1_, up_out_):
+        rr = N.refine_net(root.sub("RefineResiNet"), res1_, ref_)
+        feat = N.conv(en.sub("first_conv"), torch.cat([pf_ + rr, up_out_], 1))
+        return feat, N.unet(en.sub("unet_1"), feat), N.unet(en.sub("unet_2"), feat)
+
+    feat, f1, f2 = enhance_parts(ref, pf, res1, up_out)
+    cal.normalise("enhance.weight1.2.", lambda: _weight_logit(en.sub("weight1"), f1), 0.5, -2.0)
+    cal.normalise("enhance.weight2.2.", lambda: _weight_logit(en.sub("weight2"), f2), 0.5, -2.0)
+    cal.normalise("enhance.recon_conv1.", lambda: N.conv(en.sub("recon_conv1"), f1), 0.10, 0.5)
+    cal.normalise("enhance.recon_conv2.", lambda: N.conv(en.sub("recon_conv2"), f2), 0.10, 0.5)
+
+    def fit_rows(f1_, f2_, cur_):
+        w1, w2 = torch.sigmoid(_weight_logit(en.sub("weight1"), f1_)), torch.sigmoid(_weight_logit(en.sub("weight2"), f2_))
+        r1, r2 = N.conv(en.sub("recon_conv1"), f1_), N.conv(en.sub("recon_conv2"), f2_)
+        target = (cur_ - w1 * r1 - w2 * r2) / (1 - w1 - w2)
+        A = F.unfold(torch.cat([f1_, f2_], 1), 3, padding=1)[0].t().double()          # [HW, 128*9]
+        A = torch.cat([A, torch.ones(A.shape[0], 1, dtype=A.dtype)], 1)
+        return A, target[0].reshape(3, -1).t().double()
+
+    def ridge(rows, lam):
+        A = torch.cat([a for a, _ in rows]); T = torch.cat([t for _, t in rows])
+        G = A.t() @ A
+        reg = lam * torch.eye(G.shape[0], dtype=G.dtype) * float(G.diagonal()[:-1].mean())
+        reg[-1, -1] = 0.0
+        Wt = torch.linalg.solve(G + reg, A.t() @ T)                                    # [1153, 3]
+        cal.set("enhance.recon_conv3.weight", Wt[:-1].t().reshape(3, 128, 3, 3).float())
+        cal.set("enhance.recon_conv3.bias", Wt[-1].float())
+
+    rows = [fit_rows(f1, f2, cur)]
+    ridge(rows, 1e-3)
+    # refit on the chained frames too (steady-state branch `in_conv1(feature)`, reference = decoded frame)
+    for it in range(2):
+        o = C.DeepSVCOracle(sd); o.update(force=True)
+        ref_c, feat_c, rows = frames[0], None, []
+        for t in (1, 2, 3):
+            sm_t = synth.make_sm_fea(size, size, t)
+            taps = {}
+            mv_e, res_e = o.compress(ref_c, frames[t], sm_t, feat_c)
+            feat_n, rec, _, _ = o.decompress(ref_c, mv_e, res_e, sm_t, feat_c, taps)
+            pf_t = N.feature_extraction(fe, taps["predict"])
+            _, f1_t, f2_t = enhance_parts(ref_c, pf_t, taps["recon_res1"], taps["warp_fea"])
+            rows.append(fit_rows(f1_t, f2_t, frames[t]))
+            say(f"  fit pass {it} frame {t}: PSNR(recon,cur) {psnr(rec, frames[t]):.2f} dB, clamped "
+                f"{float(((taps['recon'] < 0) | (taps['recon'] > 1)).float().mean()):.4f}, mean {float(rec.mean()):.3f}")
+            ref_c, feat_c = rec, feat_n
+        ridge(rows, 1e-3)
+    say(f"recon_conv3 |w| max {float(sd['enhance.recon_conv3.weight'].abs().max()):.3f}")
     return cal.spec
 
 
+def write(seed_set, path):
+    spec = calibrate(seed_set)
+    out = {"recipe": f"tools/calibrate_w0.py: seed {seed_set} default init, then tensor <- tensor*mul + add (add scalar or per output "
+                     "channel), or tensor <- set (ridge-fitted recon_conv3)",
+           "tensors": {k: v for k, v in sorted(spec.items())}}
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=None, separators=(",", ":"))
+    print(f"wrote {path} ({len(out['tensors'])} tensors, {os.path.getsize(path) // 1024} KiB)")
+
+
 if __name__ == "__main__":
-    spec = calibrate("W0")
-    out = {"recipe": "tools/calibrate_w0.py: seed-0 default init x these multipliers (tensor <- tensor*mul + add)",
-           "tensors": {k: {"mul": float(v["mul"]), "add": float(v["add"])} for k, v in sorted(spec.items())}}
-    os.makedirs(os.path.dirname(synth.CALIBRATION), exist_ok=True)
-    with open(synth.CALIBRATION, "w") as f:
-        json.dump(out, f, indent=1)
-    print(f"wrote {synth.CALIBRATION} ({len(out['tensors'])} tensors)")
+    for ws in (sys.argv[1:] or ["W0", "W1"]):
+        write(ws, synth.CALIBRATIONS[ws])
