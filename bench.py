@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- encode+decode frames/s of the DeepSVC P-frame hot path at 1080p (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--size HxW] [--config 2|3] [--lanes L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f16|fp32] [--size HxW] [--config 2|3] [--lanes L]
 
 `--gpus N` with N > 1 launches N ranks itself (one fresh child process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, before
 the parent touches the GPU; the parent only relays rank 0's line); under `python -m torch.distributed.run ... bench.py --gpus N`
@@ -14,14 +14,14 @@ whose key frame is coded by the I-frame codec `ICIP2020ResB` (configs[2]).  Synt
 collective); one metrics gather at the end.
 
 Prints ONE JSON line on rank 0 (contract in the task description): value = frames of all ranks / max-over-ranks time of the
-headline leg (bf16 MFMA mode, `--lanes` GOP pipelines in flight per GPU).  Further legs of the same run, each barrier-bracketed
+headline leg (f16 MFMA mode, `--lanes` GOP pipelines in flight per GPU).  Further legs of the same run, each barrier-bracketed
 and timed the same way, are reported inside the line:
   "lanes1"      the same mode with ONE GOP in flight (strictly sequential frames): fps, and the source of `roofline` -- HIP events
                 around every launch of the dominant conv shape in that region are the kernel's own durations (with several lanes
                 in flight a launch time-shares the GPU with the other lanes' kernels; that figure is kept as `roofline.timeshared_*`);
   "parity_mode" fp32 mode (fp32 storage, fp32 MFMA): the reference's arithmetic; bitstreams byte-identical to the reference's
                 at the golden sizes (tests/test_gpu_parity.py); fps + its own roofline against the 157.3 TFLOP/s fp32 MFMA peak;
-  "bf16_vs_f32" rate / PSNR / un-clamped tensor deltas of bf16 mode against fp32 mode on the same frames, measured in this run;
+  "f16_vs_f32" rate / PSNR / un-clamped tensor deltas of f16 mode against fp32 mode on the same frames, measured in this run;
   "cpu_baseline" (+ "cpu_baseline_1thread") the CPU oracle timed on this host (N = 1 only).
 """
 import argparse
@@ -35,7 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / bf16 MFMA peaks
+PEAK_TFLOPS = {"fp32": 157.3, "f16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / f16 MFMA peaks
 HBM_PEAK = 8.0e12                                    # B/s
 # conv FLOP per padded pixel, reference structure (incl. its encoder-side recomputation)
 FLOP_PER_PX = {2: 8.571e6,      # GOP = 7: mean over the 6 P-frames (first P 8.453e6, steady-state 8.594e6)
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lanes", type=int, default=4, help="independent GOP pipelines in flight per GPU (1 = strictly sequential frames)")
-    ap.add_argument("--precision", default=os.environ.get("DSVC_PRECISION", "bf16"), choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("DSVC_PRECISION", "f16"), choices=["fp32", "f16"])
     ap.add_argument("--size", default="1080x1920")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3], help="BASELINE.json configs[1] (GOP=7, key frame given) or configs[2] (GOP=12, I-frame codec)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -267,10 +267,10 @@ def main():
             return None
         avg_ms = sum(durs) / len(durs)
         achieved = conv_flop / (avg_ms * 1e-3) / 1e12
-        esz = 2 if precision == "bf16" else 4
+        esz = 2 if precision == "f16" else 4
         r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision],
              "traffic": None,
-             "kernel": f"3x3 s1 64->64 conv @{H_pad}x{W_pad}, all epilogue variants ({'conv3x3_pp_kernel' if precision == 'bf16' else 'conv_mfma_kernel'})",
+             "kernel": f"3x3 s1 64->64 conv @{H_pad}x{W_pad}, all epilogue variants ({'conv3x3_pp_kernel' if precision == 'f16' else 'conv_mfma_kernel'})",
              "launches": len(durs), "avg_ms": avg_ms, "min_ms": min(durs),
              "algorithmic_flop": conv_flop, "algorithmic_bytes": 2.0 * H_pad * W_pad * 64 * esz,
              "hbm_view": {"achieved_GBps": 2.0 * H_pad * W_pad * 64 * esz / (avg_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK / 1e9,
@@ -296,7 +296,7 @@ def main():
         n1 = GOP if intra else GOP - 1
         t1, durs_own = timed(lanes[:1], n1)
         lanes1 = {"value": n1 * world / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1000.0 * t1 / n1, "gop_lanes": 1}
-    if side and args.precision == "bf16" and not intra:
+    if side and args.precision == "f16" and not intra:
         # ---- reference precision: fp32 mode, one GOP in flight ----
         ops.set_precision("fp32")
         try:
@@ -310,30 +310,30 @@ def main():
                       "note": "fp32 storage + v_mfma_f32_32x32x2_f32: the reference's arithmetic (PyTorch fp32); bitstreams byte-identical "
                               "to the reference's golden strings at 64/128/256 px (tests/test_gpu_parity.py)"}
             if rank == 0:
-                # ---- bf16 mode vs fp32 mode on the same frames (each chained on its own decoded state), un-clamped tensors ----
+                # ---- f16 mode vs fp32 mode on the same frames (each chained on its own decoded state), un-clamped tensors ----
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import parity_util as PU
-                b16 = lanes[0]
+                h16 = lanes[0]
                 per = []
-                st = {"bf16": (pad(b16["frames"][0], 64), None), "fp32": (pad(b16["frames"][0], 64), None)}
+                st = {"f16": (pad(h16["frames"][0], 64), None), "fp32": (pad(h16["frames"][0], 64), None)}
                 for t in (1, 2, 3):
-                    cur, sm = pad(b16["frames"][t], 64), b16["sm"][t]
+                    cur, sm = pad(h16["frames"][t], 64), h16["sm"][t]
                     got = {}
-                    for mode, L in (("bf16", b16), ("fp32", f32)):
+                    for mode, L in (("f16", h16), ("fp32", f32)):
                         ops.set_precision(mode)
                         ref, feat = st[mode]
                         L["model"].debug_taps = {}
                         mv, res = L["model"].compress(ref, cur, sm, feat)
                         feat2, recon, _, _ = L["model"].decompress(ref, mv, res, sm, feat)
                         taps, L["model"].debug_taps = L["model"].debug_taps, None
-                        got[mode] = (harness.strings_bytes(mv) + harness.strings_bytes(res), PU.psnr(harness.crop(recon, (h, w)), b16["frames"][t]),
+                        got[mode] = (harness.strings_bytes(mv) + harness.strings_bytes(res), PU.psnr(harness.crop(recon, (h, w)), h16["frames"][t]),
                                      taps["recon"].float(), feat2.float())
                         st[mode] = (recon, feat2)
-                    (nb, pb, rb, fb), (nf, pf, rf, ff) = got["bf16"], got["fp32"]
-                    per.append({"frame": t, "bytes_bf16": nb, "bytes_f32": nf, "dbpp_pct": 100.0 * (nb - nf) / nf, "psnr_f32_db": pf,
+                    (nb, pb, rb, fb), (nf, pf, rf, ff) = got["f16"], got["fp32"]
+                    per.append({"frame": t, "bytes_f16": nb, "bytes_f32": nf, "dbpp_pct": 100.0 * (nb - nf) / nf, "psnr_f32_db": pf,
                                 "dpsnr_db": pb - pf, "recon_rel_l2": float((rb - rf).norm() / rf.norm()),
                                 "feature_rel_l2": float((fb - ff).norm() / ff.norm()),
-                                "psnr_bf16_vs_f32_recon_db": PU.psnr(rb, rf),
+                                "psnr_f16_vs_f32_recon_db": PU.psnr(rb, rf),
                                 "clamped_frac_f32": float(((rf < 0) | (rf > 1)).float().mean())})
                 worst = lambda k: max((abs(p[k]) for p in per))
                 deltas = {"frames": per, "dbpp_pct": worst("dbpp_pct"), "dpsnr_db": worst("dpsnr_db"), "feature_rel_l2": worst("feature_rel_l2"),
@@ -355,7 +355,7 @@ def main():
         fps = total_frames / t_max
         traffic = None
         extra = {}
-        if args.precision == "bf16" and (h, w) == (1080, 1920) and os.path.exists(PMC_FILE):
+        if args.precision == "f16" and (h, w) == (1080, 1920) and os.path.exists(PMC_FILE):
             with open(PMC_FILE) as f:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (cannot run in-process)
                 pmc = json.load(f)
             traffic = pmc.get("hbm_bytes_per_launch_corrected")
@@ -375,7 +375,7 @@ def main():
         line = {
             "metric": name, "value": fps, "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if args.precision == "f16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {w}x{h} (padded {W_pad}x{H_pad}) GOP={GOP} "
                                    + ("(key frame coded by ICIP2020ResB + 11 P-frames), " if intra else "(key frame given + 6 P-frames), ")
                                    + f"W0 synthetic PSNR weight set, compress+decompress per frame, GOPs sharded across ranks, {args.lanes} independent "
@@ -390,10 +390,12 @@ def main():
         if parity is not None:
             line["parity_mode"] = parity
         if deltas is not None:
-            line["bf16_vs_f32"] = deltas
+            line["f16_vs_f32"] = deltas
         if not args.no_cpu_baseline and world == 1:
             import torch as _t
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_frames, _t.get_num_threads(), H_pad, W_pad)
+            # all-core leg: this process's CPU share on a 1-GPU box is 16 cores; more threads than that on a 256x256 image only
+            # add synchronisation cost (128 threads measured slower than 1)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_frames, min(_t.get_num_threads(), 16), H_pad, W_pad)
             line["cpu_baseline_1thread"] = cpu_baseline(args.cpu_sample, args.cpu_frames, 1, H_pad, W_pad)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSVC_LIB") or os.path.join(HERE, "lib", "libdsvc.so")     # DSVC_LIB: an instrumented build (tools/phase_probe.py)
 
-F32, BF16 = 0, 1
+F32, F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_HALF_TANH = range(6)
 EW_COPY, EW_ADD, EW_SUB, EW_BLEND2, EW_BLEND3, EW_CLAMP01 = range(6)
 EB_PARAMS_PER_CH = 59

@@ -1,4 +1,4 @@
-// conv1x1.hip -- bf16 pointwise (1x1) convolution as a pure streaming kernel (ResBottleneck conv1/conv3,
+// conv1x1.hip -- f16 pointwise (1x1) convolution as a pure streaming kernel (ResBottleneck conv1/conv3,
 // ConvBlockResidual.up_dim: modules.py:176,178,242; image_model.py:25,27).
 //
 // A 1x1 conv has no halo, so nothing is reused across pixels except the weights: HBM-bound (2 bytes in + 2 bytes
@@ -11,7 +11,7 @@
 //     (keeping them in registers cost occupancy: 245 VGPRs at 96->96); output channels go in pairs of N-tiles;
 //   * the epilogue is the shared fused pass (bias, activation, gated residual, second residual, cast) through a
 //     wave-private LDS slab so that stores are 16-B vectors along the NHWC channel axis -- or, for the common case
-//     (bf16 out, activation in {none, ReLU, LeakyReLU}, at most one bf16 residual: conv1 / conv3 of every
+//     (f16 out, activation in {none, ReLU, LeakyReLU}, at most one f16 residual: conv1 / conv3 of every
 //     ResBottleneckBlock), a register epilogue: operand roles swapped (D[channel][pixel]), one v_permlane32_swap per
 //     register so that each lane holds 8 consecutive channels of its pixel, bias preloaded into the accumulators, the
 //     residual prefetched one unit ahead as 16-B vectors.  The slab path ran the residual case at 2.6 TB/s (118 us for
@@ -23,11 +23,6 @@ using namespace dsvc_conv;
 
 namespace {
 
-__device__ __forceinline__ unsigned pk_bf16_1x1(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 
 // register-epilogue variant (see the header): act(x) = max(x, x * act_slope) (slope 1: none, 0: ReLU)
 // Up to two input segments of whole 32-channel chunks (the virtual torch.cat of the up-path ConvBlockResidual shortcuts);
@@ -101,7 +96,7 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
         }                                                                                                            \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
             const uint4 bw = *(const uint4*)(lds_w + ((ks >> 1) * p.Np + N0 * 32) * ROWB + b_lane + (ks & 1) * 32);   \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, a_cur[ks]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, bw), __builtin_bit_cast(h16x8, a_cur[ks]), acc, 0, 0, 0); \
         }                                                                                                            \
         _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                              \
             float v[8];                                                                                              \
@@ -120,19 +115,19 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
                     const float4 g1 = *(const float4*)(lds_bias + p.Np + N0 * 32 + 16 * P + 8 * h + 4);              \
                     const float gt[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};                            \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
-                        v[2 * j] += gt[2 * j] * __builtin_bit_cast(float, ua[j] << 16);                              \
-                        v[2 * j + 1] += gt[2 * j + 1] * __builtin_bit_cast(float, ua[j] & 0xFFFF0000u);              \
+                        v[2 * j] += gt[2 * j] * h16_lo(ua[j]);                              \
+                        v[2 * j + 1] += gt[2 * j + 1] * h16_hi(ua[j]);              \
                     }                                                                                                \
                 } else {                                                                                             \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
-                        v[2 * j] += __builtin_bit_cast(float, ua[j] << 16);                                          \
-                        v[2 * j + 1] += __builtin_bit_cast(float, ua[j] & 0xFFFF0000u);                              \
+                        v[2 * j] += h16_lo(ua[j]);                                          \
+                        v[2 * j + 1] += h16_hi(ua[j]);                              \
                     }                                                                                                \
                 }                                                                                                    \
             }                                                                                                        \
             const int co = N0 * 32 + 16 * P + 8 * h;                                                                 \
             v4u_t ov;                                                                                                \
-            ov.x = pk_bf16_1x1(v[0], v[1]); ov.y = pk_bf16_1x1(v[2], v[3]); ov.z = pk_bf16_1x1(v[4], v[5]); ov.w = pk_bf16_1x1(v[6], v[7]); \
+            ov.x = pk_h16(v[0], v[1]); ov.y = pk_h16(v[2], v[3]); ov.z = pk_h16(v[4], v[5]); ov.w = pk_h16(v[6], v[7]); \
             __builtin_amdgcn_raw_buffer_store_b128(ov, rout, (pix * opitch + (unsigned)co * 2) | ((okp && co < p.Cout) ? 0u : OOB), 0, 0); \
         }                                                                                                            \
     }
@@ -194,8 +189,8 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const ConvParams p, int nu
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                            \
             _Pragma("unroll") for (int e = 0; e < NP; ++e) {                                                         \
                 const uint4 bw = *(const uint4*)(lds_w + ((ks >> 1) * p.Np + (N0 + e) * 32) * ROWB + b_lane + (ks & 1) * 32); \
-                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[ks]),              \
-                                                                 __builtin_bit_cast(bf16x8, bw), acc[e], 0, 0, 0);   \
+                acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a_cur[ks]),              \
+                                                                 __builtin_bit_cast(h16x8, bw), acc[e], 0, 0, 0);   \
             }                                                                                                        \
         _Pragma("unroll") for (int e = 0; e < NP; ++e)                                                               \
             _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                           \
@@ -258,12 +253,12 @@ int launch_1x1_nt(hipStream_t st, const ConvParams& p, int nunits, int NT) {
 
 // returns 1 when the shape is not covered (caller falls back to the generic kernel), else DSVC_OK / error
 int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
-    if (d->compute != DSVC_BF16 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->shuffle != 1) return 1;
+    if (d->compute != DSVC_F16 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->shuffle != 1) return 1;
     if (d->nseg > 2 || d->pre_act != DSVC_ACT_NONE || !p_in.epi_vec || (d->res1_scale && d->B > 1)) return 1;
     int ctot = 0;
-    for (int s = 0; s < d->nseg; ++s) {                        // whole 32-channel chunks of aligned bf16 rows
+    for (int s = 0; s < d->nseg; ++s) {                        // whole 32-channel chunks of aligned f16 rows
         const ConvSeg& g = p_in.seg[s];
-        if (g.dtype != DSVC_BF16 || !g.vec_ok || (g.C % 32) != 0) return 1;
+        if (g.dtype != DSVC_F16 || !g.vec_ok || (g.C % 32) != 0) return 1;
         ctot += g.C;
     }
     if (ctot > 128 || d->Cout > 128) return 1;
@@ -275,14 +270,14 @@ int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_des
     p.B = 1; p.Ho = 1; p.Wo = (int)npix;                        // flat pixel list: offsets are pixel-linear
     const int nunits = (int)((npix + 31) / 32);
     const int NT = (d->Cout + 31) / 32;
-    // register epilogue: bf16 out, activation none / ReLU / LeakyReLU, at most one plain bf16 residual, 16-byte rows
+    // register epilogue: f16 out, activation none / ReLU / LeakyReLU, at most one plain f16 residual, 16-byte rows
     float act_slope = 1.f;
     const bool act_ok = d->act == DSVC_ACT_NONE || (d->act == DSVC_ACT_RELU ? (act_slope = 0.f, true)
                         : (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f ? (act_slope = d->slope, true) : false));
     auto v16 = [](const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (ld % 8) == 0; };
     static const bool direct_on = getenv("DSVC_1X1_SLAB") == nullptr;
-    if (direct_on && act_ok && d->out_dtype == DSVC_BF16 && v16(d->out, d->out_ld) && (d->Cout % 8) == 0 && !d->res2 &&
-        (!d->res1_scale || d->res1) && (!d->res1 || (d->res1_dtype == DSVC_BF16 && v16(d->res1, d->res1_ld))) && npix < (1 << 24)) {
+    if (direct_on && act_ok && d->out_dtype == DSVC_F16 && v16(d->out, d->out_ld) && (d->Cout % 8) == 0 && !d->res2 &&
+        (!d->res1_scale || d->res1) && (!d->res1 || (d->res1_dtype == DSVC_F16 && v16(d->res1, d->res1_ld))) && npix < (1 << 24)) {
         switch (sg.C / 16) {
             case 2: return launch_1x1_direct_nt<2>(st, p, nunits, NT, act_slope);
             case 4: return launch_1x1_direct_nt<4>(st, p, nunits, NT, act_slope);

@@ -1,5 +1,5 @@
-// conv3x3_pp.hip -- "ping-pong" bf16 3x3 stride-1 convolution, 64 input channels -> 32/64 output channels, bf16 NHWC in
-// and out, activation in {none, ReLU, LeakyReLU} on either side, optional bf16 residual(s): the ResBlock1 / in_conv
+// conv3x3_pp.hip -- "ping-pong" f16 3x3 stride-1 convolution, 64 input channels -> 32/64 output channels, f16 NHWC in
+// and out, activation in {none, ReLU, LeakyReLU} on either side, optional f16 residual(s): the ResBlock1 / in_conv
 // family that carries ~70 % of a 1080p P-frame's MACs (modules.py:200-204,307-311,322-340,382-418; census: 70
 // launches per frame at 1088x1920, tools/ws_census.py).
 //
@@ -27,7 +27,7 @@
 //     (A = weights, B = pixels), so D[channel][pixel] puts pixel lane&31 on the lane and 4 consecutive channels
 //     8*(reg>>2) + 4*(lane>>5) .. +3 in each register quad; one v_permlane32_swap per register exchanges quads
 //     between the two lane halves, after which every lane holds 8 CONSECUTIVE channels of its pixel; after bias,
-//     activation, residual and bf16 packing a v_permlane16_swap per packed dword regroups the lanes so that one
+//     activation, residual and f16 packing a v_permlane16_swap per packed dword regroups the lanes so that one
 //     16-B store instruction writes 64 contiguous bytes per pixel (16 cache lines per instruction instead of 32:
 //     store / residual-load issue was the longest part of the E phase).  Residuals are loaded in that same layout.  The bias is read from a
 //     small LDS table straight into the row-0 accumulators at the start of M0 and is the C operand of the first MFMAs.
@@ -50,35 +50,29 @@ __device__ __forceinline__ void buf_store16(rsrc_t r, unsigned off, uint4 v) {
 __device__ __forceinline__ float lrelu_f(float x, float slope) {
     return __builtin_amdgcn_fmed3f(x, x * slope, __builtin_inff());
 }
-// two floats -> one dword of packed bf16 (RNE), low half = a: exactly one v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// 8 packed bf16 -> act(x) = max(x, x*slope) -> 8 packed bf16 (slope 0: ReLU; 0<slope<1: LeakyReLU)
-__device__ __forceinline__ uint4 act_bf16x8(uint4 val, float slope) {
+// 8 packed f16 -> act(x) = max(x, x*slope) -> 8 packed f16 (slope 0: ReLU; 0<slope<1: LeakyReLU)
+__device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
     unsigned u[4] = {val.x, val.y, val.z, val.w};
-    if (slope == 0.f) {   // ReLU (wave-uniform): a bf16 is negative iff its int16 image is, so one packed integer max per pair
+    if (slope == 0.f) {   // ReLU (wave-uniform): a f16 is negative iff its int16 image is, so one packed integer max per pair
 #pragma unroll            // (-0.0 -> +0.0, NaNs with the sign bit set -> 0: neither occurs on this path)
         for (int k = 0; k < 4; ++k) asm("v_pk_max_i16 %0, %1, 0" : "=v"(u[k]) : "v"(u[k]));
         return make_uint4(u[0], u[1], u[2], u[3]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
-        u[k] = pk_bf16(lrelu_f(lo, slope), lrelu_f(hi, slope));
+        const float lo = h16_lo(u[k]), hi = h16_hi(u[k]);
+        u[k] = pk_h16(lrelu_f(lo, slope), lrelu_f(hi, slope));
     }
     return make_uint4(u[0], u[1], u[2], u[3]);
 }
 
 // NCH: 32-channel input chunks (2: the schedule above; 1: inputs of <= 32 channels, phases M0 | E+S0 only).
-// HEAD: narrow output head (Cout <= 8, any activation, fp32 or bf16 out, optional residual of either type): one N-tile
+// HEAD: narrow output head (Cout <= 8, any activation, fp32 or f16 out, optional residual of either type): one N-tile
 // is computed and the lanes that hold channels 0..7 store them element-wise.
 // POST: a 1x1 conv NT*32 -> NT*32 (ResBottleneckBlock.conv3) runs on the activated tile before the residual and the store: after
-// the first swap level lane (r, h) holds, as packed bf16, channels 16*kb + 8h .. +7 of pixel r for kb = 0..3 -- exactly the
+// the first swap level lane (r, h) holds, as packed f16, channels 16*kb + 8h .. +7 of pixel r for kb = 0..3 -- exactly the
 // B-operand fragment of k-block kb of a 32x32x16 MFMA -- so the tile feeds 2 x 4 MFMAs per row against weight fragments
-// read from LDS and the intermediate never leaves registers (it is rounded to bf16 as a stored tensor would be).
+// read from LDS and the intermediate never leaves registers (it is rounded to f16 as a stored tensor would be).
 template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
                                                               float pre_slope) {
@@ -163,7 +157,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
         for (int j = 0; j < PP_PFV; ++j) {
             const int pix = (gtid >> 2) + 64 * j;
             if (pix >= PP_NPATCH) continue;
-            *(uint4*)(lds_a + pix * ROWB + q * 16) = PRE ? act_bf16x8(pf[j], pre_slope) : pf[j];
+            *(uint4*)(lds_a + pix * ROWB + q * 16) = PRE ? act_h16x8(pf[j], pre_slope) : pf[j];
         }
     };
 
@@ -207,8 +201,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int m = MTW - 1 - mm;      // row 1 first: its first MFMA reads row 0's still-untouched bias
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[s2 % 3][n]),   // D[channel][pixel]
-                                                                         __builtin_bit_cast(bf16x8, af[s2 % 3][m]),
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, bf[s2 % 3][n]),   // D[channel][pixel]
+                                                                         __builtin_bit_cast(h16x8, af[s2 % 3][m]),
                                                                          (FIRST && s2 == 0) ? acc[0][n] : acc[m][n], 0, 0, 0);
                 }
             // Empty asm that "updates" every accumulator: a data + chain dependency per k-step.  The MFMA intrinsics are
@@ -222,7 +216,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
     };
 
     // epilogue lane roles (after the half-swap): pixel r of the tile row, channels 16*P + 8*h .. +7 of the N-tile
-    // byte offset of this lane's first 8-channel vector (channels 8h..) of tile row m in an NHWC bf16 tensor with row
+    // byte offset of this lane's first 8-channel vector (channels 8h..) of tile row m in an NHWC f16 tensor with row
     // pitch `ld`, or OOB; the other vectors of the pixel sit at constant byte offsets 32*P + 64*N from it (OOB + a
     // small constant stays out of range, so masked lanes need no further care).  Cout == NT*32 on this path.
     // MEMORY layout of the epilogue (after the second swap level, v_permlane16_swap on the packed dwords): lane l of
@@ -349,8 +343,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
             unsigned xa[4], xb[4];                                                                                  \
             _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(ma[d], mb[d], xa[d], xb[d])                        \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-                v0[2 * j] += __builtin_bit_cast(float, xa[j] << 16); v0[2 * j + 1] += __builtin_bit_cast(float, xa[j] & 0xFFFF0000u); \
-                v1[2 * j] += __builtin_bit_cast(float, xb[j] << 16); v1[2 * j + 1] += __builtin_bit_cast(float, xb[j] & 0xFFFF0000u); \
+                v0[2 * j] += h16_lo(xa[j]); v0[2 * j + 1] += h16_hi(xa[j]); \
+                v1[2 * j] += h16_lo(xb[j]); v1[2 * j + 1] += h16_hi(xb[j]); \
             }                                                                                                       \
             if constexpr (HAS_R2) {                                                                                 \
                 const uint4 ca = buf_load16(rr2, o_r2[M][0] + 64 * N), cb = buf_load16(rr2, o_r2[M][1] + 64 * N);   \
@@ -358,14 +352,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
                 unsigned ya[4], yb[4];                                                                              \
                 _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(na[d], nb[d], ya[d], yb[d])                    \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
-                    v0[2 * j] += __builtin_bit_cast(float, ya[j] << 16); v0[2 * j + 1] += __builtin_bit_cast(float, ya[j] & 0xFFFF0000u); \
-                    v1[2 * j] += __builtin_bit_cast(float, yb[j] << 16); v1[2 * j + 1] += __builtin_bit_cast(float, yb[j] & 0xFFFF0000u); \
+                    v0[2 * j] += h16_lo(ya[j]); v0[2 * j + 1] += h16_hi(ya[j]); \
+                    v1[2 * j] += h16_lo(yb[j]); v1[2 * j + 1] += h16_hi(yb[j]); \
                 }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
         unsigned s0[4], s1[4];                                                                                      \
         _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                               \
-            SWAP16(pk_bf16(v0[2 * d], v0[2 * d + 1]), pk_bf16(v1[2 * d], v1[2 * d + 1]), s0[d], s1[d])             \
+            SWAP16(pk_h16(v0[2 * d], v0[2 * d + 1]), pk_h16(v1[2 * d], v1[2 * d + 1]), s0[d], s1[d])             \
         buf_store16(rout, o_out[M][0] + 64 * N, make_uint4(s0[0], s0[1], s0[2], s0[3]));                            \
         buf_store16(rout, o_out[M][1] + 64 * N, make_uint4(s1[0], s1[1], s1[2], s1[3]));                            \
     }
@@ -373,7 +367,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
                 static_assert(!POST || NT == 2, "fused 1x1: 64 -> 64 channels");
 #define PP_POST_ROW(M)                                                                                              \
     {                                                                                                               \
-        unsigned bfr[4][4];          /* B fragments of k-blocks 0..3: act(conv3x3 + bias) of pixel r, packed bf16 */    \
+        unsigned bfr[4][4];          /* B fragments of k-blocks 0..3: act(conv3x3 + bias) of pixel r, packed f16 */    \
         _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                               \
             _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                         \
                 float v[8];                                                                                         \
@@ -384,7 +378,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
                     v[j] = __builtin_bit_cast(float, lo_); v[4 + j] = __builtin_bit_cast(float, hi_);               \
                 }                                                                                                   \
                 if constexpr (ACT) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = lrelu_f(v[j], act_slope); } \
-                _Pragma("unroll") for (int d = 0; d < 4; ++d) bfr[2 * n + P][d] = pk_bf16(v[2 * d], v[2 * d + 1]);    \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) bfr[2 * n + P][d] = pk_h16(v[2 * d], v[2 * d + 1]);    \
             }                                                                                                       \
         _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) {     /* accumulators of the 1x1 start as its bias */        \
             _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {                                                      \
@@ -396,7 +390,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
             _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) {                                                      \
                 const uint4 wf = *(const uint4*)(lds_w3 + ((kb >> 1) * NTN + n2 * 32 + r) * ROWB + (kb & 1) * 32 + h * 16); \
                 const uint4 bf4 = make_uint4(bfr[kb][0], bfr[kb][1], bfr[kb][2], bfr[kb][3]);                       \
-                acc[M][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, bf4), acc[M][n2], 0, 0, 0); \
+                acc[M][n2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wf), __builtin_bit_cast(h16x8, bf4), acc[M][n2], 0, 0, 0); \
             }                                                                                                       \
     }
                 PP_POST_ROW(0) PP_POST_ROW(1)
@@ -464,11 +458,11 @@ bool vec16_ok(const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (l
 
 // returns 1 when the shape is not covered (caller tries conv3x3_ws / the generic kernel), else DSVC_OK / error
 int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
-    if (d->compute != DSVC_BF16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
+    if (d->compute != DSVC_F16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
     if (p_in.nchunks < 1 || p_in.nchunks > 2 || p_in.nseg > 2 || d->res1_scale) return 1;
     for (int s = 0; s < p_in.nseg; ++s) {                          // every pixel's chunk row is an aligned run of 16-B vectors
         const ConvSeg& sg = p_in.seg[s];
-        if (sg.dtype != DSVC_BF16 || (sg.C % 8) != 0 || !vec16_ok(sg.ptr, sg.ld)) return 1;
+        if (sg.dtype != DSVC_F16 || (sg.C % 8) != 0 || !vec16_ok(sg.ptr, sg.ld)) return 1;
         if (p_in.nchunks == 2 && (sg.C % 32) != 0) return 1;
     }
     ConvParams p = p_in;
@@ -480,8 +474,8 @@ int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     if (d->post_weight) {                  // fused ResBottleneck tail: conv3x3 -> act -> conv1x1 -> + residual
         float a_slope;
         if (p.nchunks != 2 || d->Cout != 64 || d->pre_act != DSVC_ACT_NONE || d->res2 || !slope_of(d->act, d->slope, &a_slope)) return 1;
-        if (d->out_dtype != DSVC_BF16 || !vec16_ok(d->out, d->out_ld) || ((uintptr_t)d->post_weight & 15) != 0) return 1;
-        if (d->res1 && (d->res1_dtype != DSVC_BF16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
+        if (d->out_dtype != DSVC_F16 || !vec16_ok(d->out, d->out_ld) || ((uintptr_t)d->post_weight & 15) != 0) return 1;
+        if (d->res1 && (d->res1_dtype != DSVC_F16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
         const bool act1 = d->act != DSVC_ACT_NONE;
         if (d->res1) return act1 ? launch_pp<2, 2, false, false, true, true, false, true>(st, p, ntiles, a_slope, 1.f)
                                  : launch_pp<2, 2, false, false, false, true, false, true>(st, p, ntiles, 1.f, 1.f);
@@ -494,9 +488,9 @@ int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
                               : launch_pp<1, 1, true, false, false, false, false>(st, p, ntiles, 1.f, 1.f);
     }
     if (d->Cout != 32 && d->Cout != 64) return 1;
-    if (d->out_dtype != DSVC_BF16 || !vec16_ok(d->out, d->out_ld)) return 1;
-    if (d->res1 && (d->res1_dtype != DSVC_BF16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
-    if (d->res2 && (!d->res1 || d->res2_dtype != DSVC_BF16 || !vec16_ok(d->res2, d->res2_ld))) return 1;
+    if (d->out_dtype != DSVC_F16 || !vec16_ok(d->out, d->out_ld)) return 1;
+    if (d->res1 && (d->res1_dtype != DSVC_F16 || !vec16_ok(d->res1, d->res1_ld))) return 1;
+    if (d->res2 && (!d->res1 || d->res2_dtype != DSVC_F16 || !vec16_ok(d->res2, d->res2_ld))) return 1;
     float act_slope, pre_slope;
     if (!slope_of(d->act, d->slope, &act_slope) || !slope_of(d->pre_act, d->slope, &pre_slope)) return 1;
     const bool pre = d->pre_act != DSVC_ACT_NONE, act = d->act != DSVC_ACT_NONE;

@@ -1,4 +1,4 @@
-// conv3x3_ws.hip -- bf16 3x3 stride-1 convolution with <= 64 input channels at large resolution: the shape family
+// conv3x3_ws.hip -- f16 3x3 stride-1 convolution with <= 64 input channels at large resolution: the shape family
 // that carries ~2/3 of a P-frame's MACs (ResBlock1 / ResBottleneck conv2 /
 // in_conv / weight heads of modules.py:177,200-204,307-311,322-340,382-418).
 //
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) conv3x3_ws_ker
                 if ((tid >> 2) + (NTHR / 4) * j < WS_NPATCH && iy >= 0 && iy < H && ix >= 0 && ix < W) {
                     float vals[EPV];
                     load_vec<EPV>(sg, (((int64_t)b * H + iy) * W + ix) * sg.ld, c0 + q * EPV, vals);
-                    pf[j] = pack_vec<__bf16, EPV>(vals);
+                    pf[j] = pack_vec<h16, EPV>(vals);
                 }
             }
         }
@@ -110,12 +110,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) conv3x3_ws_ker
             const int pix = (tid >> 2) + (NTHR / 4) * j;
             if (pix >= WS_NPATCH) continue;
             uint4 val = pf[j];
-            if (pre_act != DSVC_ACT_NONE) {   // ResBlock1's leading ReLU / LeakyReLU on the packed bf16 pairs
+            if (pre_act != DSVC_ACT_NONE) {   // ResBlock1's leading ReLU / LeakyReLU on the packed f16 pairs
                 unsigned u[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
-                    u[k] = (unsigned)f32_to_bf16_bits(fmaxf(lo, lo * pre_sl)) | ((unsigned)f32_to_bf16_bits(fmaxf(hi, hi * pre_sl)) << 16);
+                    const float lo = h16_lo(u[k]), hi = h16_hi(u[k]);
+                    u[k] = pk_h16(fmaxf(lo, lo * pre_sl), fmaxf(hi, hi * pre_sl));
                 }
                 val = make_uint4(u[0], u[1], u[2], u[3]);
             }
@@ -173,11 +173,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) conv3x3_ws_ker
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         if constexpr (DIRECT)   // swapped roles: D[channel][pixel], the pixel lands on the lane
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[s2 & 1][n]),
-                                                                                 __builtin_bit_cast(bf16x8, af[s2 & 1][m]), acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, bf[s2 & 1][n]),
+                                                                                 __builtin_bit_cast(h16x8, af[s2 & 1][m]), acc[m][n], 0, 0, 0);
                         else
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s2 & 1][m]),
-                                                                                 __builtin_bit_cast(bf16x8, bf[s2 & 1][n]), acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, af[s2 & 1][m]),
+                                                                                 __builtin_bit_cast(h16x8, bf[s2 & 1][n]), acc[m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 
@@ -235,7 +235,7 @@ int launch_ws(hipStream_t st, const ConvParams& p, int ntiles) {
 
 // returns 1 when the shape is not covered (caller falls back to the generic kernel), else DSVC_OK / error
 int dsvc_conv3x3_ws_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
-    if (d->compute != DSVC_BF16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
+    if (d->compute != DSVC_F16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
     if (p_in.nchunks > 2 || d->Cout > 64) return 1;
     ConvParams p = p_in;
     p.tiles_x = (p.Wo + 31) / 32;
@@ -243,7 +243,7 @@ int dsvc_conv3x3_ws_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if (ntiles < 512) return 1;            // small images: the generic kernel's finer tiling fills the chip better
     bool fast = true;
-    for (int s = 0; s < p.nseg; ++s) fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == DSVC_BF16 && (p.seg[s].C % 8) == 0;
+    for (int s = 0; s < p.nseg; ++s) fast = fast && p.seg[s].vec_ok && p.seg[s].dtype == DSVC_F16 && (p.seg[s].C % 8) == 0;
     const int NT = d->Cout > 32 ? 2 : 1;
     // Direct stores from swapped-operand accumulators are implemented but measured SLOWER than the LDS-transposed epilogue
     // (285 vs 257 us on 64->64 @1088x1920: each store instruction touches 32 cache lines); opt-in for experiments only.

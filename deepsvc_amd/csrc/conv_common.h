@@ -66,7 +66,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 struct EpiRsrc {      // one descriptor per operand (an absent residual borrows the output's; its offsets are all OOB)
     rsrc_t out, r1, r2;
-    bool out_f32, r1_f32, r1_bf16, r2_f32, r2_bf16;
+    bool out_f32, r1_f32, r1_h16, r2_f32, r2_h16;
 };
 __device__ __forceinline__ EpiRsrc make_epi_rsrc(const ConvParams& p) {
     EpiRsrc R;
@@ -74,15 +74,15 @@ __device__ __forceinline__ EpiRsrc make_epi_rsrc(const ConvParams& p) {
     R.r1 = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? p.res1_bytes : p.out_bytes);
     R.r2 = make_rsrc(p.res2 ? p.res2 : p.out, p.res2 ? p.res2_bytes : p.out_bytes);
     R.out_f32 = p.out_dtype == DSVC_F32;
-    R.r1_f32 = p.res1 && p.res1_dtype == DSVC_F32; R.r1_bf16 = p.res1 && p.res1_dtype == DSVC_BF16;
-    R.r2_f32 = p.res2 && p.res2_dtype == DSVC_F32; R.r2_bf16 = p.res2 && p.res2_dtype == DSVC_BF16;
+    R.r1_f32 = p.res1 && p.res1_dtype == DSVC_F32; R.r1_h16 = p.res1 && p.res1_dtype == DSVC_F16;
+    R.r2_f32 = p.res2 && p.res2_dtype == DSVC_F32; R.r2_h16 = p.res2 && p.res2_dtype == DSVC_F16;
     return R;
 }
 
 
 // ---- fused epilogue pass over one wave-private LDS slab, specialised per activation -------------------------
 // Lane -> (channel group g = lane % GPP fixed for the whole pass, pixel lanes step 64/GPP): bias/gate are loaded once,
-// residuals and outputs move as 16-byte (fp32) / 8-byte (bf16) vectors along the channel axis.
+// residuals and outputs move as 16-byte (fp32) / 8-byte (f16) vectors along the channel axis.
 template <int ACT>
 __device__ __forceinline__ float act_t(float v, float slope) {
     if constexpr (ACT == DSVC_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -100,8 +100,8 @@ __device__ __forceinline__ void load4(const void* base, int dtype, int vec, int6
             o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
         } else {
             const uint2 t = *(const uint2*)((const unsigned short*)base + off);
-            o[0] = __builtin_bit_cast(float, t.x << 16); o[1] = __builtin_bit_cast(float, t.x & 0xFFFF0000u);
-            o[2] = __builtin_bit_cast(float, t.y << 16); o[3] = __builtin_bit_cast(float, t.y & 0xFFFF0000u);
+            o[0] = h16_lo(t.x); o[1] = h16_hi(t.x);
+            o[2] = h16_lo(t.y); o[3] = h16_hi(t.y);
         }
     } else {
 #pragma unroll
@@ -148,8 +148,8 @@ __device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* 
                     *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     uint2 u;
-                    u.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-                    u.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+                    u.x = pk_h16(v[0], v[1]);
+                    u.y = pk_h16(v[2], v[3]);
                     *(uint2*)((unsigned short*)p.out + oo) = u;
                 }
             } else {
@@ -202,19 +202,20 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
         if constexpr (HAS_RES) {
             const unsigned e1 = spix * p.res1_ld + lane_1, e2 = spix * p.res2_ld + lane_2;
             const v4u_t f1 = __builtin_amdgcn_raw_buffer_load_b128(R.r1, (ok && R.r1_f32) ? e1 * 4 : OOB, 0, 0);
-            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_bf16) ? e1 * 2 : OOB, 0, 0);
+            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_h16) ? e1 * 2 : OOB, 0, 0);
             const v4u_t f2 = __builtin_amdgcn_raw_buffer_load_b128(R.r2, (ok && R.r2_f32) ? e2 * 4 : OOB, 0, 0);
-            const v2u_t h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_bf16) ? e2 * 2 : OOB, 0, 0);
+            const v2u_t h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_h16) ? e2 * 2 : OOB, 0, 0);
             // NB: lanes are copied to scalars first -- __builtin_bit_cast applied directly to an ext-vector element
             // (f1.y) is compiled as a cast of element 0 by hipcc 7.2.
             const unsigned a1[4] = {f1.x, f1.y, f1.z, f1.w}, a2[4] = {f2.x, f2.y, f2.z, f2.w};
-            const unsigned b1[4] = {h1.x << 16, h1.x & 0xFFFF0000u, h1.y << 16, h1.y & 0xFFFF0000u};
-            const unsigned b2[4] = {h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+            const unsigned h1x = h1.x, h1y = h1.y, h2x = h2.x, h2y = h2.y;
+            const float b1[4] = {h16_lo(h1x), h16_hi(h1x), h16_lo(h1y), h16_hi(h1y)};
+            const float b2[4] = {h16_lo(h2x), h16_hi(h2x), h16_lo(h2y), h16_hi(h2y)};
             float r1[4], r2[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                r1[j] = __builtin_bit_cast(float, a1[j]) + __builtin_bit_cast(float, b1[j]);
-                r2[j] = __builtin_bit_cast(float, a2[j]) + __builtin_bit_cast(float, b2[j]);
+                r1[j] = __builtin_bit_cast(float, a1[j]) + b1[j];
+                r2[j] = __builtin_bit_cast(float, a2[j]) + b2[j];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += gate[j] * r1[j] + r2[j];
@@ -224,8 +225,8 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
         of.x = __builtin_bit_cast(unsigned, v[0]); of.y = __builtin_bit_cast(unsigned, v[1]);
         of.z = __builtin_bit_cast(unsigned, v[2]); of.w = __builtin_bit_cast(unsigned, v[3]);
         v2u_t ob;
-        ob.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-        ob.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        ob.x = pk_h16(v[0], v[1]);
+        ob.y = pk_h16(v[2], v[3]);
         __builtin_amdgcn_raw_buffer_store_b128(of, R.out, (ok && R.out_f32) ? eo * 4 : OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64(ob, R.out, (ok && !R.out_f32) ? eo * 2 : OOB, 0, 0);
     }
@@ -259,7 +260,7 @@ __device__ __forceinline__ void run_epilogue(const ConvParams& p, const EpiRsrc&
 
 // ---- direct epilogue for the SWAPPED operand order (A = weights, B = pixels) -------------------------------------------
 // D[row = output channel][col = pixel]: lane (r = lane&31, h = lane>>5) owns pixel r of the M-tile and, per register
-// group g = reg>>2, the 4 consecutive channels cbase + 8g + 4h .. +3 -- exactly one 16-B (fp32) / 8-B (bf16) vector
+// group g = reg>>2, the 4 consecutive channels cbase + 8g + 4h .. +3 -- exactly one 16-B (fp32) / 8-B (f16) vector
 // of the NHWC output.  No LDS transposition, no barrier; straight-line buffer ops (masked lanes / absent operands via OOB).
 template <int ACT, bool HAS_RES>
 __device__ __forceinline__ void epilogue_direct_tile(const ConvParams& p, const EpiRsrc& R, const rsrc_t& rbias, const f32x16& acc,
@@ -276,24 +277,24 @@ __device__ __forceinline__ void epilogue_direct_tile(const ConvParams& p, const 
         if constexpr (HAS_RES) {
             const unsigned e1 = opix * p.res1_ld + co, e2 = opix * p.res2_ld + co;
             const v4u_t f1 = __builtin_amdgcn_raw_buffer_load_b128(R.r1, (ok && R.r1_f32) ? e1 * 4 : OOB, 0, 0);
-            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_bf16) ? e1 * 2 : OOB, 0, 0);
+            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_h16) ? e1 * 2 : OOB, 0, 0);
             const v4u_t f2 = __builtin_amdgcn_raw_buffer_load_b128(R.r2, (ok && R.r2_f32) ? e2 * 4 : OOB, 0, 0);
-            const v2u_t h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_bf16) ? e2 * 2 : OOB, 0, 0);
+            const v2u_t h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_h16) ? e2 * 2 : OOB, 0, 0);
             const unsigned a1[4] = {f1.x, f1.y, f1.z, f1.w}, a2[4] = {f2.x, f2.y, f2.z, f2.w};
-            const unsigned b1[4] = {h1.x << 16, h1.x & 0xFFFF0000u, h1.y << 16, h1.y & 0xFFFF0000u};
-            const unsigned b2[4] = {h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+            const unsigned h1x = h1.x, h1y = h1.y, h2x = h2.x, h2y = h2.y;
+            const float b1[4] = {h16_lo(h1x), h16_hi(h1x), h16_lo(h1y), h16_hi(h1y)};
+            const float b2[4] = {h16_lo(h2x), h16_hi(h2x), h16_lo(h2y), h16_hi(h2y)};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                v[j] += (__builtin_bit_cast(float, a1[j]) + __builtin_bit_cast(float, b1[j])) +
-                        (__builtin_bit_cast(float, a2[j]) + __builtin_bit_cast(float, b2[j]));
+                v[j] += (__builtin_bit_cast(float, a1[j]) + b1[j]) + (__builtin_bit_cast(float, a2[j]) + b2[j]);
         }
         const unsigned eo = opix * p.out_ld + co;
         v4u_t of;
         of.x = __builtin_bit_cast(unsigned, v[0]); of.y = __builtin_bit_cast(unsigned, v[1]);
         of.z = __builtin_bit_cast(unsigned, v[2]); of.w = __builtin_bit_cast(unsigned, v[3]);
         v2u_t ob;
-        ob.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-        ob.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        ob.x = pk_h16(v[0], v[1]);
+        ob.y = pk_h16(v[2], v[3]);
         __builtin_amdgcn_raw_buffer_store_b128(of, R.out, (ok && R.out_f32) ? eo * 4 : OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64(ob, R.out, (ok && !R.out_f32) ? eo * 2 : OOB, 0, 0);
     }
@@ -322,7 +323,7 @@ __device__ __forceinline__ void run_epilogue_direct(const ConvParams& p, const E
 
 template <typename CT> struct CTraits;
 template <> struct CTraits<float> { static constexpr int KCE = 16, EPV = 4; };
-template <> struct CTraits<__bf16> { static constexpr int KCE = 32, EPV = 8; };
+template <> struct CTraits<h16> { static constexpr int KCE = 32, EPV = 8; };
 
 template <int EPV>
 __device__ __forceinline__ void load_vec(const ConvSeg& sg, int64_t off, int c, float (&v)[EPV]) {
@@ -342,16 +343,16 @@ __device__ __forceinline__ void load_vec(const ConvSeg& sg, int64_t off, int c, 
                 unsigned u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[2 * j] = __builtin_bit_cast(float, u[j] << 16);
-                    v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u);
+                    v[2 * j] = h16_lo(u[j]);
+                    v[2 * j + 1] = h16_hi(u[j]);
                 }
             } else {
                 uint2 t = *(const uint2*)p;
                 unsigned u[2] = {t.x, t.y};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    v[2 * j] = __builtin_bit_cast(float, u[j] << 16);
-                    v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u);
+                    v[2 * j] = h16_lo(u[j]);
+                    v[2 * j + 1] = h16_hi(u[j]);
                 }
             }
         }
@@ -370,7 +371,7 @@ __device__ __forceinline__ uint4 pack_vec(const float (&v)[EPV]) {
         unsigned u[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            u[j] = (unsigned)f32_to_bf16_bits(v[2 * j]) | ((unsigned)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+            u[j] = pk_h16(v[2 * j], v[2 * j + 1]);
         return make_uint4(u[0], u[1], u[2], u[3]);
     }
 }

@@ -8,7 +8,7 @@
 //   GEMM M = output pixels, N = output channels, K = taps x input channels.
 //   A workgroup (4 waves) owns a tile of (4*MT) x 32 output pixels and NT*32 output channels.
 //   Wave w owns tile rows [w*MT, w*MT+MT): each row of 32 pixels is one MFMA M-tile.
-//   K is walked in 64-byte "chunks" of input channels (16 fp32 / 32 bf16).  For one chunk the
+//   K is walked in 64-byte "chunks" of input channels (16 fp32 / 32 f16).  For one chunk the
 //   input HALO PATCH ((TH-1)*s+kh) x ((TW-1)*s+kw) pixels is staged ONCE into LDS and every tap
 //   reads it at a shifted pixel offset -- HBM/L2 sees each input element once per tile, not kh*kw times.
 //   LDS rows (one pixel of the patch, or one output channel of a tap's weights) are 64 B of data
@@ -17,7 +17,7 @@
 //   takes bytes [32h + 16ks, +16) of row r.  The same byte->k assignment is used for A and B, so
 //   the K order inside a chunk is a free permutation.
 //   fp32 compute: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), 4 MFMAs per 16-B fragment pair.
-//   bf16 compute: v_mfma_f32_32x32x16_bf16, 1 MFMA per 16-B fragment pair, fp32 accumulate.
+//   f16 compute: v_mfma_f32_32x32x16_f16, 1 MFMA per 16-B fragment pair, fp32 accumulate.
 //   Epilogue (fused): + bias, activation, + residual (optionally gated per channel: SELayer),
 //   + second residual, optional PixelShuffle(2) scatter, cast to the output storage type.
 #include <cstdlib>
@@ -26,7 +26,6 @@
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
-int dsvc_conv3x3_direct_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 #ifdef DSVC_PHASE_PROBE
 // Build with DSVC_BUILD_DEFINES=-DDSVC_PHASE_PROBE (deepsvc_amd/build.py) to get per-phase shader-clock totals of wave 0 of
@@ -55,11 +54,11 @@ namespace {
 using namespace dsvc_conv;
 
 // REGEPI: the MFMA operands are swapped (A = weights, B = pixels), so a lane ends up with 16 output channels of ONE pixel
-// and the epilogue needs no LDS: one 32-lane swap turns them into two runs of 8 consecutive channels = two 16-byte bf16
+// and the epilogue needs no LDS: one 32-lane swap turns them into two runs of 8 consecutive channels = two 16-byte f16
 // stores (the slab epilogue -- accumulators through LDS, two extra barriers per pass -- is ~20 % of a workgroup's time on
-// the large convs, tools/phase_probe.py).  Taken for bf16 output, whole 32-channel tiles, act in {none, relu, lrelu},
-// at most one bf16 residual; everything else keeps the slab epilogue.
-// PF > 0 (with REGEPI, bf16 storage, one staging batch per chunk): the input patch of the NEXT channel chunk is prefetched
+// the large convs, tools/phase_probe.py).  Taken for f16 output, whole 32-channel tiles, act in {none, relu, lrelu},
+// at most one f16 residual; everything else keeps the slab epilogue.
+// PF > 0 (with REGEPI, f16 storage, one staging batch per chunk): the input patch of the NEXT channel chunk is prefetched
 // into PF registers per thread during the last MFMA phase of the current chunk, like the weights.
 template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false, int PF = 0>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
@@ -135,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     };
     w_issue(0, 0, true);
     uint4 pv[PF > 0 ? PF : 1];
-    auto p_issue = [&](int ch2, bool any) {          // same-type (bf16) storage only; every lane masked when !any (branch-free)
+    auto p_issue = [&](int ch2, bool any) {          // same-type (f16) storage only; every lane masked when !any (branch-free)
         if constexpr (PF > 0) {
             int s2i = 0;
             if (p.nseg > 1 && ch2 >= p.seg[1].chunk0) s2i = 1;
@@ -171,8 +170,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
-                        u[k] = (unsigned)f32_to_bf16_bits(fmaxf(lo, lo * sl)) | ((unsigned)f32_to_bf16_bits(fmaxf(hi, hi * sl)) << 16);
+                        const float lo = h16_lo(u[k]), hi = h16_hi(u[k]);
+                        u[k] = pk_h16(fmaxf(lo, lo * sl), fmaxf(hi, hi * sl));
                     }
                     v = make_uint4(u[0], u[1], u[2], u[3]);
                 }
@@ -204,8 +203,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         bool staged = false;
         if constexpr (PF > 0) { p_commit(); staged = true; }
         if constexpr (PF == 0 && FAST && sizeof(CT) == 2) {
-            // fp32 storage feeding the bf16 MFMA (the entropy scan's fp32 latents): two 16-B loads per quarter, batched like
-            // the same-type path, rounded to bf16 (RNE, as pack_vec does) on the way into LDS
+            // fp32 storage feeding the f16 MFMA (the entropy scan's fp32 latents): two 16-B loads per quarter, batched like
+            // the same-type path, rounded to f16 (RNE, as pack_vec does) on the way into LDS
             if (sg.dtype == DSVC_F32) {
                 staged = true;
                 constexpr int PC = 4;
@@ -284,8 +283,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                                 const float f = __builtin_bit_cast(float, u[k]);
                                 u[k] = __builtin_bit_cast(unsigned, fmaxf(f, f * sl));
                             } else {
-                                const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
-                                u[k] = (unsigned)f32_to_bf16_bits(fmaxf(lo, lo * sl)) | ((unsigned)f32_to_bf16_bits(fmaxf(hi, hi * sl)) << 16);
+                                const float lo = h16_lo(u[k]), hi = h16_hi(u[k]);
+                                u[k] = pk_h16(fmaxf(lo, lo * sl), fmaxf(hi, hi * sl));
                             }
                         }
                         v[j] = make_uint4(u[0], u[1], u[2], u[3]);
@@ -398,9 +397,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                                 for (int j = 0; j < 4; ++j)
                                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[m][n], 0, 0, 0);
                             } else {
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(bf16x8, REGEPI ? f.b[ks][n] : f.a[ks][m]),
-                                    __builtin_bit_cast(bf16x8, REGEPI ? f.a[ks][m] : f.b[ks][n]), acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    __builtin_bit_cast(h16x8, REGEPI ? f.b[ks][n] : f.a[ks][m]),
+                                    __builtin_bit_cast(h16x8, REGEPI ? f.a[ks][m] : f.b[ks][n]), acc[m][n], 0, 0, 0);
                             }
                         }
             };
@@ -421,8 +420,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, REGEPI ? f.b[n] : f.a[m]), __builtin_bit_cast(bf16x8, REGEPI ? f.a[m] : f.b[n]), acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(h16x8, REGEPI ? f.b[n] : f.a[m]), __builtin_bit_cast(h16x8, REGEPI ? f.a[m] : f.b[n]), acc[m][n], 0, 0, 0);
                 };
                 FragsK g0, g1;
                 read_step(g0, 0);
@@ -513,10 +512,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v0[2 * j] += __builtin_bit_cast(float, ru0[j] << 16); v0[2 * j + 1] += __builtin_bit_cast(float, ru0[j] & 0xFFFF0000u);
-                    v1[2 * j] += __builtin_bit_cast(float, ru1[j] << 16); v1[2 * j + 1] += __builtin_bit_cast(float, ru1[j] & 0xFFFF0000u);
-                    o0[j] = (unsigned)f32_to_bf16_bits(v0[2 * j]) | ((unsigned)f32_to_bf16_bits(v0[2 * j + 1]) << 16);
-                    o1[j] = (unsigned)f32_to_bf16_bits(v1[2 * j]) | ((unsigned)f32_to_bf16_bits(v1[2 * j + 1]) << 16);
+                    v0[2 * j] += h16_lo(ru0[j]); v0[2 * j + 1] += h16_hi(ru0[j]);
+                    v1[2 * j] += h16_lo(ru1[j]); v1[2 * j + 1] += h16_hi(ru1[j]);
+                    o0[j] = pk_h16(v0[2 * j], v0[2 * j + 1]);
+                    o1[j] = pk_h16(v1[2 * j], v1[2 * j + 1]);
                 }
                 const v4u_t s0 = {o0[0], o0[1], o0[2], o0[3]}, s1 = {o1[0], o1[1], o1[2], o1[3]};
                 __builtin_amdgcn_raw_buffer_store_b128(s0, R.out, ((opix * p.out_ld + co0) * 2u) | pm, 0, 0);
@@ -585,13 +584,13 @@ int launch_nt(hipStream_t st, const ConvParams& p, int NT, int ngroups, size_t l
 template <typename CT>
 int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, int ngroups, size_t lds) {
     if constexpr (sizeof(CT) == 2) {
-        if (p.regepi) {                       // register epilogue (see conv_mfma_kernel): large bf16 convs only
+        if (p.regepi) {                       // register epilogue (see conv_mfma_kernel): large f16 convs only
             if (MT == 4) return launch_cfg<CT, 4, 2, true, true>(st, p, ngroups, lds);
             if (NT == 2) return p.patchpf ? launch_cfg<CT, 2, 2, true, true, 6>(st, p, ngroups, lds) : launch_cfg<CT, 2, 2, true, true>(st, p, ngroups, lds);
             if (NT == 3) return launch_cfg<CT, 2, 3, true, true>(st, p, ngroups, lds);
             return launch_cfg<CT, 2, 4, true, true>(st, p, ngroups, lds);
         }
-        if (MT == 4) return launch_cfg<CT, 4, 2, true>(st, p, ngroups, lds);      // 16x32-pixel tiles: bf16, vector staging, 64 output channels per group
+        if (MT == 4) return launch_cfg<CT, 4, 2, true>(st, p, ngroups, lds);      // 16x32-pixel tiles: f16, vector staging, 64 output channels per group
     }
     if (fast) return MT == 2 ? launch_nt<CT, 2, true>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, true>(st, p, NT, ngroups, lds);
     return MT == 2 ? launch_nt<CT, 2, false>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, false>(st, p, NT, ngroups, lds);
@@ -616,7 +615,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     DSVC_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv2d: bad shape B=%d H=%d W=%d Cout=%d", d->B, d->H, d->W, d->Cout);
     DSVC_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->kh <= 7 && d->kw <= 7, "conv2d: kernel %dx%d unsupported", d->kh, d->kw);
     DSVC_REQUIRE(d->stride == 1 || d->stride == 2, "conv2d: stride %d unsupported", d->stride);
-    DSVC_REQUIRE(d->compute == DSVC_F32 || d->compute == DSVC_BF16, "conv2d: bad compute type %d", d->compute);
+    DSVC_REQUIRE(d->compute == DSVC_F32 || d->compute == DSVC_F16, "conv2d: bad compute type %d", d->compute);
     DSVC_REQUIRE(d->weight && d->out, "conv2d: null weight/out");
     DSVC_REQUIRE(d->shuffle == 1 || (d->shuffle == 2 && d->Cout % 4 == 0), "conv2d: shuffle=%d Cout=%d", d->shuffle, d->Cout);
     DSVC_REQUIRE(!(d->shuffle == 2 && (d->res2 || d->res1_scale)), "conv2d: shuffle with res2/gate unsupported");
@@ -632,7 +631,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     for (int s = 0; s < d->nseg; ++s) {
         const dsvc_seg& in = d->in[s];
         DSVC_REQUIRE(in.ptr && in.C > 0 && in.ld >= (d->s2d ? in.C / 4 : in.C), "conv2d: segment %d ptr/C/ld invalid (C=%d ld=%d)", s, in.C, in.ld);
-        DSVC_REQUIRE(in.dtype == DSVC_F32 || in.dtype == DSVC_BF16, "conv2d: segment %d dtype", s);
+        DSVC_REQUIRE(in.dtype == DSVC_F32 || in.dtype == DSVC_F16, "conv2d: segment %d dtype", s);
         const int es = dsvc_esize(in.dtype);
         if (d->s2d)
             DSVC_REQUIRE(in.dtype == d->compute && in.C % kce == 0 && ((uintptr_t)in.ptr & 15) == 0 && ((int64_t)in.ld * es) % 16 == 0,
@@ -677,7 +676,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     p.res2 = d->res2; p.res2_ld = d->res2_ld; p.res2_dtype = d->res2_dtype;
     p.post_w = d->post_weight; p.post_bias = d->post_bias;
     p.out = d->out; p.out_ld = d->out_ld; p.out_dtype = d->out_dtype; p.shuffle = d->shuffle;
-    // 4-channel vector access (16 B fp32 / 8 B bf16) is legal when base and pixel pitch keep that alignment
+    // 4-channel vector access (16 B fp32 / 8 B f16) is legal when base and pixel pitch keep that alignment
     auto vec4_ok = [](const void* ptr, int ld, int dtype) {
         const int bytes = 4 * dsvc_esize(dtype);
         return ptr != nullptr && ((uintptr_t)ptr % bytes) == 0 && (ld % 4) == 0;
@@ -699,9 +698,9 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     for (int s = 0; s < d->nseg; ++s)
         fast = fast && p.seg[s].vec_ok &&
                ((p.seg[s].dtype == d->compute && (p.seg[s].C % (kce / 4)) == 0) ||
-                (d->compute == DSVC_BF16 && p.seg[s].dtype == DSVC_F32 && (p.seg[s].C % 4) == 0 && !d->s2d));   // converted while staged
+                (d->compute == DSVC_F16 && p.seg[s].dtype == DSVC_F32 && (p.seg[s].C % 4) == 0 && !d->s2d));   // converted while staged
 
-    // ---- bf16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
+    // ---- f16 3x3 C_in<=64 convs at large resolution: persistent kernel with LDS-resident weights ----
     DsvcOptions opt = g_dsvc_opt;
     if (p.s2d || per_item) {                // only the general kernel's staging understands the space-to-depth view / item offsets
         DSVC_REQUIRE(fast, "conv2d: s2d and batch_inner need the vector staging path (16-byte aligned rows, whole 4/8-channel quarters)");
@@ -712,19 +711,15 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
         DSVC_REQUIRE(rc != 1, "conv2d: post_weight (fused 1x1) is not supported for this shape / type combination");
         return rc;
     }
-    if (opt.specialised && opt.direct) {    // small images (entropy-scan nets): barrier-free kernel, fragments straight from L2
-        const int rc = dsvc_conv3x3_direct_try((hipStream_t)stream, p, d);
-        if (rc != 1) return rc;             // 1 = not applicable, try the next kernel
-    }
-    if (opt.specialised && opt.conv1x1) {   // bf16 pointwise convs: streaming kernel, no LDS staging
+    if (opt.specialised && opt.conv1x1) {   // f16 pointwise convs: streaming kernel, no LDS staging
         const int rc = dsvc_conv1x1_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;
     }
-    if (opt.specialised && opt.pp) {        // 64-channel bf16 ResBlock family: two phase-skewed wave groups per CU
+    if (opt.specialised && opt.pp) {        // 64-channel f16 ResBlock family: two phase-skewed wave groups per CU
         const int rc = dsvc_conv3x3_pp_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;
     }
-    if (opt.specialised && opt.ws) {        // other large bf16 3x3 convs with <= 64 input channels: LDS-resident weights
+    if (opt.specialised && opt.ws) {        // other large f16 3x3 convs with <= 64 input channels: LDS-resident weights
         const int rc = dsvc_conv3x3_ws_try((hipStream_t)stream, p, d);
         if (rc != 1) return rc;
     }
@@ -741,16 +736,16 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     static const int mt_thr = getenv("DSVC_MT_THR") ? atoi(getenv("DSVC_MT_THR")) : 400;
     if (nblocks(MT, NT) < mt_thr && MT == 2) MT = 1;
     while (nblocks(MT, NT) < mt_thr && NT > 1) NT = (NT + 1) / 2;
-    // large bf16 stride-1 convs with 64 output channels per group: 16x32-pixel tiles -- 0.75 instead of 1.0 ds_read_b128 per
+    // large f16 stride-1 convs with 64 output channels per group: 16x32-pixel tiles -- 0.75 instead of 1.0 ds_read_b128 per
     // MFMA and half the weight staging per pixel.  Worth only ~4 % (3x3 64+64->64 @1088x1920: 491 -> 471 us): the PMC
     // counters put the LDS at ~35 % busy and the MFMA pipe at 36 %, i.e. the kernel waits on barriers and staging latency
     // with two workgroups per CU, not on LDS bandwidth
     // (96 output channels: 16 rows spill -- 192 accumulator registers --, and a 12-row variant measured 237 vs 152 us)
     bool same_type = true;
     for (int s = 0; s < d->nseg; ++s) same_type = same_type && p.seg[s].dtype == d->compute;
-    // 3x3 convs over bf16 storage take the patch-prefetch variant of the 8x32 tiling instead (64+64->64: 452 vs 466 us)
-    const bool pf_shape = opt.patch_prefetch && opt.reg_epilogue && same_type && d->kh == 3 && d->kw == 3 && d->out_dtype == DSVC_BF16;
-    if (MT == 2 && NT == 2 && fast && d->compute == DSVC_BF16 && d->stride == 1 && !pf_shape && nblocks(4, NT) >= opt.tall_min_tiles) {
+    // 3x3 convs over f16 storage take the patch-prefetch variant of the 8x32 tiling instead (64+64->64: 452 vs 466 us)
+    const bool pf_shape = opt.patch_prefetch && opt.reg_epilogue && same_type && d->kh == 3 && d->kw == 3 && d->out_dtype == DSVC_F16;
+    if (MT == 2 && NT == 2 && fast && d->compute == DSVC_F16 && d->stride == 1 && !pf_shape && nblocks(4, NT) >= opt.tall_min_tiles) {
         const size_t a4 = (size_t)(15 + d->kh) * (31 + d->kw) * ROWB;
         if (a4 + (size_t)d->kw * NT * 32 * ROWB <= 78 * 1024) MT = 4;           // still two workgroups per CU
     }
@@ -767,19 +762,19 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > budget) p.tapg = d->kw;
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > 160 * 1024) p.tapg = 1;
     {   // the weight prefetch registers of the kernel variant (WP in conv_mfma_kernel) hold one whole staging step
-        const int wp = (MT == 4 || d->compute != DSVC_BF16) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
+        const int wp = (MT == 4 || d->compute != DSVC_F16) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
         if (wp > 0 && (p.tapg * NT + 1) / 2 > wp) p.tapg = 2 * wp / NT;
     }
     const size_t lds_main = lds_a + (size_t)p.tapg * NT * 32 * ROWB;
 
     {
         auto al16 = [](const void* q, int ld) { return ((uintptr_t)q & 15) == 0 && (ld % 8) == 0; };
-        p.regepi = opt.reg_epilogue && fast && d->compute == DSVC_BF16 && (MT == 4 || (MT == 2 && NT >= 2)) && d->out_dtype == DSVC_BF16 &&
+        p.regepi = opt.reg_epilogue && fast && d->compute == DSVC_F16 && (MT == 4 || (MT == 2 && NT >= 2)) && d->out_dtype == DSVC_F16 &&
                    d->shuffle == 1 && (d->Cout % 32) == 0 && al16(d->out, d->out_ld) && !d->res2 && !d->res1_scale &&
-                   (!d->res1 || (d->res1_dtype == DSVC_BF16 && al16(d->res1, d->res1_ld))) &&
+                   (!d->res1 || (d->res1_dtype == DSVC_F16 && al16(d->res1, d->res1_ld))) &&
                    (d->act == DSVC_ACT_NONE || d->act == DSVC_ACT_RELU || (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f));
     }
-    {   // patch prefetch variant: bf16 storage everywhere, one staging batch (<= 6 vectors per thread) per chunk
+    {   // patch prefetch variant: f16 storage everywhere, one staging batch (<= 6 vectors per thread) per chunk
         // (96 output channels: 256 registers with spills, 142 vs 129 us; with the k-step fragment pipeline to free registers 137 vs
         //  121 us for the tap-level pipeline without patch prefetch -- not taken)
         p.patchpf = p.regepi && opt.patch_prefetch && MT == 2 && NT == 2 && same_type && PH * PW <= 6 * 64;
@@ -790,5 +785,5 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
 
     hipStream_t st = (hipStream_t)stream;
     if (d->compute == DSVC_F32) return launch_ct<float>(st, p, MT, NT, fast, ngroups, lds);
-    return launch_ct<__bf16>(st, p, MT, NT, fast, ngroups, lds);
+    return launch_ct<h16>(st, p, MT, NT, fast, ngroups, lds);
 }

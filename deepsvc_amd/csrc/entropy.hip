@@ -128,7 +128,7 @@ __global__ void eb_dequantize_kernel(const int32_t* sym, const float* params, in
         store_elem(zhat, dt, (b * HW + p) * zhat_ld + c, (float)sym[i] + params[(int64_t)c * DSVC_EB_PARAMS_PER_CH + 58]);
     }
 }
-inline bool dt_ok(int dt) { return dt == DSVC_F32 || dt == DSVC_BF16; }
+inline bool dt_ok(int dt) { return dt == DSVC_F32 || dt == DSVC_F16; }
 }  // namespace
 
 extern "C" int dsvc_gc_quantize(void* stream, const void* y, int32_t y_ld, const void* mu, int32_t mu_ld,

@@ -22,8 +22,6 @@ extern "C" int dsvc_version(void) { return DSVC_VERSION; }
 static int env_flag(const char* name) { return getenv(name) != nullptr; }
 DsvcOptions g_dsvc_opt = {
     /*specialised*/ !env_flag("DSVC_NO_WS"), /*pp*/ !env_flag("DSVC_NO_PP"), /*ws*/ 1, /*conv1x1*/ 1,
-    /*direct*/ env_flag("DSVC_DIRECT"),      // small-image direct kernel: measured slower end to end, opt-in
-    /*direct_max_pix*/ getenv("DSVC_DIRECT_MAX_PIX") ? atoi(getenv("DSVC_DIRECT_MAX_PIX")) : 16384,
     /*ws_waves4*/ env_flag("DSVC_WS_WAVES4"), /*ws_direct_store*/ env_flag("DSVC_WS_DIRECT"),
     /*tall_min_tiles*/ getenv("DSVC_TALL_MIN_TILES") ? atoi(getenv("DSVC_TALL_MIN_TILES")) : 1024,
     /*reg_epilogue*/ !env_flag("DSVC_NO_REGEPI"), /*patch_prefetch*/ !env_flag("DSVC_NO_PATCHPF")};
@@ -31,7 +29,7 @@ DsvcOptions g_dsvc_opt = {
 extern "C" int dsvc_set_option(const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
         {"specialised", &g_dsvc_opt.specialised}, {"pp", &g_dsvc_opt.pp}, {"ws", &g_dsvc_opt.ws},
-        {"conv1x1", &g_dsvc_opt.conv1x1}, {"direct", &g_dsvc_opt.direct}, {"direct_max_pix", &g_dsvc_opt.direct_max_pix},
+        {"conv1x1", &g_dsvc_opt.conv1x1}, 
         {"ws_waves4", &g_dsvc_opt.ws_waves4}, {"ws_direct_store", &g_dsvc_opt.ws_direct_store},
         {"tall_min_tiles", &g_dsvc_opt.tall_min_tiles}, {"reg_epilogue", &g_dsvc_opt.reg_epilogue},
         {"patch_prefetch", &g_dsvc_opt.patch_prefetch}};
@@ -76,10 +74,10 @@ extern "C" int dsvc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t pr
     return DSVC_OK;
 }
 
-static inline uint16_t f32_to_bf16_host(float f) {  // round to nearest even; NaN stays NaN
-    uint32_t u; std::memcpy(&u, &f, 4);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+static inline uint16_t f32_to_h16_host(float f) {  // IEEE binary16, round to nearest even (same rounding as v_cvt_f16_f32)
+    const _Float16 h = (_Float16)f;
+    uint16_t u; std::memcpy(&u, &h, 2);
+    return u;
 }
 
 // OIHW fp32 -> [chunk][tap][Np][64 B] of the compute type; chunks never straddle input segments.
@@ -87,7 +85,7 @@ extern "C" int dsvc_conv_pack_weights(const float* w, int32_t Cout, int32_t nseg
                                       int32_t kh, int32_t kw, int32_t compute, void* packed) {
     DSVC_REQUIRE(w && packed && segC, "conv_pack_weights: null argument");
     DSVC_REQUIRE(Cout > 0 && nseg >= 1 && nseg <= 3 && kh >= 1 && kw >= 1, "conv_pack_weights: bad shape");
-    DSVC_REQUIRE(compute == DSVC_F32 || compute == DSVC_BF16, "conv_pack_weights: bad compute type");
+    DSVC_REQUIRE(compute == DSVC_F32 || compute == DSVC_F16, "conv_pack_weights: bad compute type");
     const int kce = compute == DSVC_F32 ? 16 : 32;
     const int64_t Np = (Cout + 31) / 32 * 32;
     const int taps = kh * kw;
@@ -108,7 +106,7 @@ extern "C" int dsvc_conv_pack_weights(const float* w, int32_t Cout, int32_t nseg
                         if (cl >= segC[s]) break;
                         const float v = w[((int64_t)n * Cin + (cbase + cl)) * taps + t];
                         if (compute == DSVC_F32) ((float*)row)[e] = v;
-                        else ((uint16_t*)row)[e] = f32_to_bf16_host(v);
+                        else ((uint16_t*)row)[e] = f32_to_h16_host(v);
                     }
                 }
             }

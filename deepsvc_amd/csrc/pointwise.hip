@@ -88,10 +88,10 @@ __global__ void pool2x2_kernel(int mode, const void* in, int in_ld, void* out, i
     }
 }
 
-// 16 bytes per thread (8 bf16 / 4 fp32 channels): the element-wise kernel above moves 2-4 bytes per lane (1.5 TB/s at 1080p)
-template <bool BF16>
+// 16 bytes per thread (8 f16 / 4 fp32 channels): the element-wise kernel above moves 2-4 bytes per lane (1.5 TB/s at 1080p)
+template <bool H16>
 __global__ void pool2x2_vec_kernel(int mode, const void* in, int in_ld, void* out, int out_ld, int B, int H, int W, int C) {
-    constexpr int V = BF16 ? 8 : 4;
+    constexpr int V = H16 ? 8 : 4;
     const int Ho = H / 2, Wo = W / 2, CV = C / V;
     const int64_t total = (int64_t)B * Ho * Wo * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -105,13 +105,13 @@ __global__ void pool2x2_vec_kernel(int mode, const void* in, int in_ld, void* ou
         float v[4][8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint4 u = BF16 ? *(const uint4*)((const unsigned short*)in + offs[k]) : *(const uint4*)((const float*)in + offs[k]);
+            const uint4 u = H16 ? *(const uint4*)((const unsigned short*)in + offs[k]) : *(const uint4*)((const float*)in + offs[k]);
             const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if constexpr (BF16) {
-                    v[k][2 * j] = __builtin_bit_cast(float, w[j] << 16);
-                    v[k][2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xFFFF0000u);
+                if constexpr (H16) {
+                    v[k][2 * j] = h16_lo(w[j]);
+                    v[k][2 * j + 1] = h16_hi(w[j]);
                 } else {
                     v[k][j] = __builtin_bit_cast(float, w[j]);
                 }
@@ -121,12 +121,12 @@ __global__ void pool2x2_vec_kernel(int mode, const void* in, int in_ld, void* ou
 #pragma unroll
         for (int j = 0; j < V; ++j)
             o[j] = mode == 0 ? ((v[0][j] + v[1][j]) + (v[2][j] + v[3][j])) * 0.25f : fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
-        if constexpr (BF16) {
+        if constexpr (H16) {
             uint4 u;
-            u.x = (unsigned)f32_to_bf16_bits(o[0]) | ((unsigned)f32_to_bf16_bits(o[1]) << 16);
-            u.y = (unsigned)f32_to_bf16_bits(o[2]) | ((unsigned)f32_to_bf16_bits(o[3]) << 16);
-            u.z = (unsigned)f32_to_bf16_bits(o[4]) | ((unsigned)f32_to_bf16_bits(o[5]) << 16);
-            u.w = (unsigned)f32_to_bf16_bits(o[6]) | ((unsigned)f32_to_bf16_bits(o[7]) << 16);
+            u.x = pk_h16(o[0], o[1]);
+            u.y = pk_h16(o[2], o[3]);
+            u.z = pk_h16(o[4], o[5]);
+            u.w = pk_h16(o[6], o[7]);
             *(uint4*)((unsigned short*)out + pix * out_ld + c) = u;
         } else {
             *(float4*)((float*)out + pix * out_ld + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -151,9 +151,9 @@ __global__ void pixel_shuffle_nchw_kernel(const float* in, void* out, int out_ld
 }
 
 // Same op, one thread per OUTPUT PIXEL and 8 channels: lanes walk the source x (64 consecutive floats of one plane per load,
-// coalesced) and write their pixel's 8 channels as one 16-byte (bf16) / two 16-byte (fp32) stores -- the element-wise kernel
+// coalesced) and write their pixel's 8 channels as one 16-byte (f16) / two 16-byte (fp32) stores -- the element-wise kernel
 // above wrote 2 bytes per thread at a 32-byte stride (216 us for the 1080p inter-layer feature, ~0.9 TB/s).
-template <bool BF16>
+template <bool H16>
 __global__ void pixel_shuffle_nchw_vec8_kernel(const float* __restrict__ in, void* out, int out_ld, int B, int Co, int Hin, int Win, int r) {
     const int64_t total = (int64_t)B * Hin * r * r * Win * (Co / 8);
     const int64_t plane = (int64_t)Hin * Win;
@@ -170,12 +170,12 @@ __global__ void pixel_shuffle_nchw_vec8_kernel(const float* __restrict__ in, voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * r * r * plane];
         const int64_t o = ((b * Hin * r + yi * r + ry) * (int64_t)Win * r + xi * r + rx) * out_ld + c8;
-        if constexpr (BF16) {
+        if constexpr (H16) {
             uint4 u;
-            u.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-            u.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-            u.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
-            u.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+            u.x = pk_h16(v[0], v[1]);
+            u.y = pk_h16(v[2], v[3]);
+            u.z = pk_h16(v[4], v[5]);
+            u.w = pk_h16(v[6], v[7]);
             *(uint4*)((unsigned short*)out + o) = u;
         } else {
             *(float4*)((float*)out + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -225,7 +225,7 @@ __global__ void nhwc_to_nchw_kernel(const void* in, int in_ld, int in_dt, float*
 
 struct Opnd { const void* p; int ld, dt; };
 constexpr int kSeBlocks = 512;   // partial sums per image
-// 8 consecutive channels as floats <-> one 16-B (bf16) or two 16-B (fp32) vectors
+// 8 consecutive channels as floats <-> one 16-B (f16) or two 16-B (fp32) vectors
 __device__ __forceinline__ void load8(const void* p, int dt, int64_t off, float (&v)[8]) {
     if (dt == DSVC_F32) {
         const float4 a = *(const float4*)((const float*)p + off), b = *(const float4*)((const float*)p + off + 4);
@@ -234,7 +234,7 @@ __device__ __forceinline__ void load8(const void* p, int dt, int64_t off, float 
         const uint4 t = *(const uint4*)((const unsigned short*)p + off);
         const unsigned u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[2 * j] = __builtin_bit_cast(float, u[j] << 16); v[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xFFFF0000u); }
+        for (int j = 0; j < 4; ++j) { v[2 * j] = h16_lo(u[j]); v[2 * j + 1] = h16_hi(u[j]); }
     }
 }
 __device__ __forceinline__ void store8(void* p, int dt, int64_t off, const float (&v)[8]) {
@@ -244,12 +244,12 @@ __device__ __forceinline__ void store8(void* p, int dt, int64_t off, const float
     } else {
         unsigned u[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) u[j] = (unsigned)f32_to_bf16_bits(v[2 * j]) | ((unsigned)f32_to_bf16_bits(v[2 * j + 1]) << 16);
+        for (int j = 0; j < 4; ++j) u[j] = pk_h16(v[2 * j], v[2 * j + 1]);
         *(uint4*)((unsigned short*)p + off) = make_uint4(u[0], u[1], u[2], u[3]);
     }
 }
 inline bool vec8_ok(const void* p, int ld, int dt, int C) {
-    return p && (C % 8) == 0 && (ld % 8) == 0 && ((uintptr_t)p % 16) == 0 && (dt == DSVC_F32 || dt == DSVC_BF16);
+    return p && (C % 8) == 0 && (ld % 8) == 0 && ((uintptr_t)p % 16) == 0 && (dt == DSVC_F32 || dt == DSVC_F16);
 }
 
 // warp, 8 channels per thread, 16-B accesses (the 64-channel feature warp of InterLayerPrediction, modules.py:429)
@@ -449,7 +449,7 @@ __global__ void reduce_final_kernel(const float* partial, int n, double* out) {
 }
 
 inline Opnd mk(const dsvc_operand* o) { return o ? Opnd{o->ptr, o->ld, o->dtype} : Opnd{nullptr, 0, 0}; }
-inline bool dt_ok(int dt) { return dt == DSVC_F32 || dt == DSVC_BF16; }
+inline bool dt_ok(int dt) { return dt == DSVC_F32 || dt == DSVC_F16; }
 
 }  // namespace
 
@@ -488,9 +488,9 @@ extern "C" int dsvc_pool2x2(void* stream, int32_t mode, const void* in, int32_t 
     DSVC_REQUIRE(in && out && (mode == 0 || mode == 1) && dt_ok(dtype), "pool2x2: bad argument");
     DSVC_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0 && in_ld >= C && out_ld >= C, "pool2x2: bad shape H=%d W=%d", H, W);
     const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
-    const int V = dtype == DSVC_BF16 ? 8 : 4, es = dsvc_esize(dtype);
+    const int V = dtype == DSVC_F16 ? 8 : 4, es = dsvc_esize(dtype);
     if (C % V == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && ((int64_t)in_ld * es) % 16 == 0 && ((int64_t)out_ld * es) % 16 == 0) {
-        if (dtype == DSVC_BF16)
+        if (dtype == DSVC_F16)
             hipLaunchKernelGGL(pool2x2_vec_kernel<true>, dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
         else
             hipLaunchKernelGGL(pool2x2_vec_kernel<false>, dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
@@ -507,7 +507,7 @@ extern "C" int dsvc_pixel_shuffle_nchw(void* stream, const float* in, void* out,
     DSVC_REQUIRE(in && out && B > 0 && Cout > 0 && Hin > 0 && Win > 0 && r >= 1 && out_ld >= Cout && dt_ok(out_dtype), "pixel_shuffle: bad argument");
     const int64_t n = (int64_t)B * Cout * Hin * r * Win * r;
     if (Cout % 8 == 0 && ((uintptr_t)out & 15) == 0 && ((int64_t)out_ld * dsvc_esize(out_dtype)) % 16 == 0) {
-        if (out_dtype == DSVC_BF16)
+        if (out_dtype == DSVC_F16)
             hipLaunchKernelGGL(pixel_shuffle_nchw_vec8_kernel<true>, dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);
         else
             hipLaunchKernelGGL(pixel_shuffle_nchw_vec8_kernel<false>, dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);

@@ -169,8 +169,8 @@ def _run_stack(stack, segments, out=None, hidden_act=N.ACT_GELU, hidden_slope=0.
     convs = [m for m in stack if isinstance(m, Conv2d)]
     x = segments
     for c in convs[:-1]:
-        # hidden activations in the storage type: in bf16 mode they would be rounded to bf16 when staged for the MFMA
-        # anyway (same single rounding), and bf16 storage puts the next layer on the conv's fast staging path
+        # hidden activations in the storage type: in f16 mode they would be rounded to f16 when staged for the MFMA
+        # anyway (same single rounding), and f16 storage puts the next layer on the conv's fast staging path
         x = c.run(x, act=hidden_act, slope=hidden_slope, out_dtype=ops.RT.storage)
     return convs[-1].run(x, out, out_dtype=F32, **last_epilogue)
 

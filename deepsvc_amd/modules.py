@@ -53,11 +53,11 @@ class Conv2d(nn.Conv2d):
         return cache[key]
 
     def _s2d_ok(self, phys_inputs):
-        """bf16 mode: conv5x5/s2 runs as a 3x3/s1 conv over the space-to-depth view of its inputs (include/dsvc.h: s2d) when
-        every input is bf16 with 16-byte pixel rows: no 25-tap weight re-staging per tile, and 8-channel segments fill a
+        """f16 mode: conv5x5/s2 runs as a 3x3/s1 conv over the space-to-depth view of its inputs (include/dsvc.h: s2d) when
+        every input is f16 with 16-byte pixel rows: no 25-tap weight re-staging per tile, and 8-channel segments fill a
         32-channel chunk exactly (8 channels x 4 phases) instead of being padded to it."""
-        if not (ops.S2D[0] and ops.RT.compute == N.BF16 and self.kernel_size == (5, 5) and self.stride == (2, 2) and self.padding == (2, 2)
-                and all(a.dtype == torch.bfloat16 and a.C % 8 == 0 and a.ld % 8 == 0 and a.ptr % 16 == 0 and a.H % 2 == 0 and a.W % 2 == 0
+        if not (ops.S2D[0] and ops.RT.compute == N.F16 and self.kernel_size == (5, 5) and self.stride == (2, 2) and self.padding == (2, 2)
+                and all(a.dtype == torch.float16 and a.C % 8 == 0 and a.ld % 8 == 0 and a.ptr % 16 == 0 and a.H % 2 == 0 and a.W % 2 == 0
                         for a in phys_inputs)):
             return False
         # the view executes 36 MACs per input channel (9 taps x 4 phases, 11 of the 36 are structural zeros), the direct
@@ -66,7 +66,7 @@ class Conv2d(nn.Conv2d):
         return 36 * sum(a.C for a in phys_inputs) <= 25 * sum(-(-a.C // 32) * 32 for a in phys_inputs)
 
     def _pack_small_runs(self, inputs):
-        """bf16 mode: maximal runs of small fp32 inputs (frames, flows: 2-3 channels each) are merged into one bf16
+        """f16 mode: maximal runs of small fp32 inputs (frames, flows: 2-3 channels each) are merged into one f16
         buffer padded with zero channels to a multiple of 8, so the conv's fast 16-byte staging path applies.
         Returns (physical inputs, logical channel split, physical channel split)."""
         small = lambda a: a.dtype == torch.float32 and a.C < 32 and (a.C % 8 != 0)
@@ -81,7 +81,7 @@ class Conv2d(nn.Conv2d):
             cache = self.__dict__.setdefault("_small_cache", {})
             key = (len(phys), x0.B, x0.H, x0.W, pc, str(x0.device))
             if key not in cache:          # zero-initialised once: the padding channels are never written afterwards
-                cache[key] = Act(torch.zeros((x0.B, x0.H, x0.W, pc), dtype=torch.bfloat16, device=x0.device))
+                cache[key] = Act(torch.zeros((x0.B, x0.H, x0.W, pc), dtype=torch.float16, device=x0.device))
             phys.append(ops.pack_small_inputs(run, cache[key]))
             logical.append(lc)
             physical.append(pc)
@@ -100,7 +100,7 @@ class Conv2d(nn.Conv2d):
 
     def run(self, inputs, out=None, **epilogue):
         inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
-        if ops.RT.compute == N.BF16 and any(a.dtype == torch.float32 and a.C % 8 != 0 and a.C < 32 for a in inputs):
+        if ops.RT.compute == N.F16 and any(a.dtype == torch.float32 and a.C % 8 != 0 and a.C < 32 for a in inputs):
             phys, logical, physical = self._pack_small_runs(inputs)
             if len(phys) <= 3:
                 return ops.conv2d(self._packed(logical, phys[0].device, physical, s2d=self._s2d_ok(phys)), phys, out, **epilogue)
@@ -250,11 +250,11 @@ class ResBottleneckBlock(nn.Module):
 
     def _fuse_tail_ok(self, x, o, out):
         """conv2 -> act -> conv3 -> + x as ONE launch (the 1x1 rides on the 3x3 kernel's epilogue, include/dsvc.h:
-        post_weight) where the two-group 3x3 kernel applies: bf16 mode, 64 channels, bf16 16-byte-aligned tensors,
+        post_weight) where the two-group 3x3 kernel applies: f16 mode, 64 channels, f16 16-byte-aligned tensors,
         >= 1024 tiles of 8x32 pixels.  Saves a full read + write of the activation per block."""
-        if not (ops.FUSE_1X1[0] and ops.RT.compute == N.BF16 and self.conv2.in_channels == 64 and self.conv2.out_channels == 64):
+        if not (ops.FUSE_1X1[0] and ops.RT.compute == N.F16 and self.conv2.in_channels == 64 and self.conv2.out_channels == 64):
             return False
-        ok = lambda a: a.dtype == torch.bfloat16 and a.C == 64 and a.ld % 8 == 0 and a.ptr % 16 == 0
+        ok = lambda a: a.dtype == torch.float16 and a.C == 64 and a.ld % 8 == 0 and a.ptr % 16 == 0
         tiles = x.B * (-(-x.H // 8)) * (-(-x.W // 32))
         return ok(x) and ok(o) and (out is None or ok(out)) and tiles >= 1024 and x.B * x.H * x.W < (1 << 24)
 
@@ -262,7 +262,7 @@ class ResBottleneckBlock(nn.Module):
         o = self.conv1.run(x, act=self._act, slope=self._slope)
         if self._fuse_tail_ok(x, o, out):
             post = self.conv3._packed([64], o.device)
-            return self.conv2.run(o, out, act=self._act, slope=self._slope, res1=x, post=post, out_dtype=torch.bfloat16)
+            return self.conv2.run(o, out, act=self._act, slope=self._slope, res1=x, post=post, out_dtype=torch.float16)
         o = self.conv2.run(o, act=self._act, slope=self._slope)
         return self.conv3.run(o, out, res1=x)
 

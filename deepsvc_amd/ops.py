@@ -12,7 +12,7 @@ import torch
 
 from . import _native as N
 
-_TORCH2CODE = {torch.float32: N.F32, torch.bfloat16: N.BF16}
+_TORCH2CODE = {torch.float32: N.F32, torch.float16: N.F16}
 
 
 class Precision:
@@ -25,10 +25,10 @@ class Precision:
     def set(self, mode):
         if mode == "fp32":
             self.compute, self.storage = N.F32, torch.float32
-        elif mode == "bf16":
-            self.compute, self.storage = N.BF16, torch.bfloat16
+        elif mode == "f16":
+            self.compute, self.storage = N.F16, torch.float16
         else:
-            raise ValueError(f"unknown precision mode {mode!r} (use 'fp32' or 'bf16')")
+            raise ValueError(f"unknown precision mode {mode!r} (use 'fp32' or 'f16')")
         self.mode = mode
 
     mode = "fp32"
@@ -58,8 +58,8 @@ import threading as _threading
 
 _fork_pools = _threading.local()
 ITEM_SCAN = [_os.environ.get("DSVC_NO_ITEM_SCAN", "0") != "1"]   # mean+scale stacks of a scan level as one launch per layer
-FUSE_1X1 = [_os.environ.get("DSVC_NO_FUSE_1X1", "") == ""]   # ResBottleneck conv2 -> act -> conv3 -> + x in one launch (bf16, 64 ch)
-S2D = [_os.environ.get("DSVC_NO_S2D", "") == ""]       # conv5x5/s2 through the space-to-depth view (bf16 mode)
+FUSE_1X1 = [_os.environ.get("DSVC_NO_FUSE_1X1", "") == ""]   # ResBottleneck conv2 -> act -> conv3 -> + x in one launch (f16, 64 ch)
+S2D = [_os.environ.get("DSVC_NO_S2D", "") == ""]       # conv5x5/s2 through the space-to-depth view (f16 mode)
 USE_FORKS = [_os.environ.get("DSVC_FORKS", "") != ""]   # opt-in: measured 17.15 vs 17.6 fps (event edges cost more than the overlap)
 
 
@@ -195,7 +195,7 @@ class PackedConv:
         self.s2d = bool(s2d)
         if self.s2d:                         # conv5x5/s2 -> 3x3/s1 over the space-to-depth view (include/dsvc.h: s2d)
             assert (self.kh, self.kw, stride, pad) == (5, 5, 2, 2)
-            w, seg_channels = s2d_weights(w, seg_channels, 8 if compute == N.BF16 else 4)
+            w, seg_channels = s2d_weights(w, seg_channels, 8 if compute == N.F16 else 4)
             self.kh = self.kw = 3
             stride, pad = 1, 1
         self.segC = tuple(int(c) for c in seg_channels)
@@ -370,8 +370,8 @@ def items_ok(acts):
     for a in acts:
         es = a.buf.element_size()
         same = a.code == RT.compute
-        q = (8 if RT.compute == N.BF16 else 2) if same else 4
-        if a.ptr % 16 or (a.ld * es) % 16 or a.C % q or not (same or (RT.compute == N.BF16 and a.dtype == torch.float32)):
+        q = (8 if RT.compute == N.F16 else 2) if same else 4
+        if a.ptr % 16 or (a.ld * es) % 16 or a.C % q or not (same or (RT.compute == N.F16 and a.dtype == torch.float32)):
             return False
     return True
 

@@ -34,7 +34,7 @@ extern "C" {
 
 /* element types of activation storage / MFMA compute */
 #define DSVC_F32 0
-#define DSVC_BF16 1
+#define DSVC_F16 1      /* IEEE binary16 storage / MFMA operands (fp32 accumulation) */
 
 /* fused activations */
 #define DSVC_ACT_NONE 0
@@ -50,14 +50,14 @@ int dsvc_version(void);
 int dsvc_device_count(void);
 /* Kernel-selection switches of dsvc_conv2d, for A/B measurements and tests from one process (no reference
  * counterpart: the reference has one cuDNN path).  Keys: "specialised" (1: conv1x1 / conv3x3_ws / conv3x3_pp /
- * conv3x3_direct may take a launch, 0: generic kernel only), "pp", "ws", "conv1x1", "direct" (each 0/1),
- * "direct_max_pix", "ws_waves4", "ws_direct_store", "tall_min_tiles" (the generic kernel uses 16x32-pixel tiles for bf16
+ * may take a launch, 0: generic kernel only), "pp", "ws", "conv1x1" (each 0/1),
+ * "ws_waves4", "ws_direct_store", "tall_min_tiles" (the generic kernel uses 16x32-pixel tiles for f16
  * stride-1 convs with 64 output channels per group from this many tiles on; a huge value turns them off), "reg_epilogue" (1: the
  * generic kernel's LDS-free epilogue where it applies), "patch_prefetch" (1: ... with the next chunk's input patch prefetched).  Defaults come from
- * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_DIRECT, DSVC_DIRECT_MAX_PIX, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
+ * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
  * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
- * fp32 mode; in bf16 mode they agree within the bf16 tolerance of the tests. */
+ * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------
@@ -70,7 +70,7 @@ typedef struct dsvc_seg {
     const void* ptr; /* channel 0 of pixel (0,0) of image 0 of this input segment */
     int32_t C;       /* channels taken from this segment */
     int32_t ld;      /* elements between consecutive pixels */
-    int32_t dtype;   /* DSVC_F32 / DSVC_BF16 */
+    int32_t dtype;   /* DSVC_F32 / DSVC_F16 */
 } dsvc_seg;
 
 typedef struct dsvc_conv_desc {
@@ -79,7 +79,7 @@ typedef struct dsvc_conv_desc {
     dsvc_seg in[3];
     int32_t kh, kw, stride, pad;
     int32_t Cout;         /* conv output channels (before depth-to-space) */
-    int32_t compute;      /* DSVC_F32: v_mfma_f32_32x32x2_f32; DSVC_BF16: v_mfma_f32_32x32x16_bf16 */
+    int32_t compute;      /* DSVC_F32: v_mfma_f32_32x32x2_f32; DSVC_F16: v_mfma_f32_32x32x16_f16 */
     const void* weight;   /* device buffer produced by dsvc_conv_pack_weights for this compute type */
     const float* bias;    /* device [Cout] fp32, or NULL */
     int32_t pre_act;      /* activation applied to the INPUT while staging (ResBlock1 first_layer) */
@@ -93,7 +93,7 @@ typedef struct dsvc_conv_desc {
     void* out; int32_t out_ld, out_dtype;
     /* s2d = 1: the inputs are read through a SPACE-TO-DEPTH view: B, H, W describe the view grid, every view pixel (Y, X)
      * is the 2x2 block of pixels (2Y+py, 2X+px) of a (2H x 2W) NHWC image with row pitch in[s].ld, and view channel
-     * g*4*V + (2*py+px)*V + c is channel g*V + c of that pixel (V = 8 for bf16 compute, 4 for fp32: one 16-byte vector).
+     * g*4*V + (2*py+px)*V + c is channel g*V + c of that pixel (V = 8 for f16 compute, 4 for fp32: one 16-byte vector).
      * in[s].C counts VIEW channels (4x the image's).  Requires kh = kw = 3, stride 1, pad 1, input storage == compute type,
      * 16-byte aligned rows.  This is how conv5x5/s2 (compressai conv(), image_model.py:53-66,344-358,376-382) runs: the
      * 5x5 stride-2 kernel is exactly a 3x3 stride-1 kernel over this view (weights remapped once on the host), which
@@ -104,7 +104,7 @@ typedef struct dsvc_conv_desc {
      *     out = post_weight * act(conv + bias) + post_bias + res1
      * post_weight: packed weights (dsvc_conv_pack_weights) of a 1x1 conv Cout -> Cout, post_bias: device [Cout] fp32 or NULL.
      * The intermediate act(conv + bias) is rounded to the compute type exactly as if it had been stored and re-read.
-     * Supported where the two-group 3x3 kernel applies (bf16, 64 -> 64 channels, >= 1024 tiles, bf16 NHWC in/out/res1,
+     * Supported where the two-group 3x3 kernel applies (f16, 64 -> 64 channels, >= 1024 tiles, f16 NHWC in/out/res1,
      * no res2 / gate / shuffle); dsvc_conv2d fails with DSVC_E_ARG otherwise -- callers fuse only then. */
     const void* post_weight; const float* post_bias;
     /* batch_inner > 0: the B batch items are INDEPENDENT convs of identical shape in one launch (the slice scan runs the

@@ -28,10 +28,11 @@ def psnr(a, b):
 
 # fp32 mode vs the CPU oracle / the reference's golden tensors: both sides evaluate the same fp32 graph, only the summation
 # order inside the convolutions differs.  Observed on MI355X (see the printed table of each test): rel-L2 <= 3e-6 everywhere.
-FP32_BOUNDS = dict(feature=5e-5, recon=5e-5, warped=5e-5, predict=5e-5, latent=5e-5)
-# bf16 mode (bf16 MFMA operands + bf16 activation storage, fp32 accumulation, fp32 latents/heads) vs the fp32 oracle:
-# observed 3e-3..1.2e-2 depending on the depth of the chain in front of the tensor.
-BF16_BOUNDS = dict(feature=3e-2, recon=2e-2, warped=2e-2, predict=2e-2, latent=3e-2)
+FP32_BOUNDS = dict(feature=1e-5, recon=1e-5, warped=1e-5, predict=1e-5, latent=1e-5)
+# f16 mode (IEEE binary16 MFMA operands + activation storage, fp32 accumulation, fp32 latents/heads) vs fp32: every stored
+# activation carries a 2^-12 relative rounding error.  (bfloat16 storage showed 3.6e-3..9e-3 here and drifted 0.05-0.1 dB in
+# PSNR over three chained frames -- outside the north_star tolerance -- which is why the fast mode is binary16.)
+F16_BOUNDS = dict(feature=4e-3, recon=4e-3, warped=4e-3, predict=4e-3, latent=4e-3)
 
 
 def check_frame(tag, got, want, bounds=FP32_BOUNDS, report=None):
@@ -51,7 +52,7 @@ def check_frame(tag, got, want, bounds=FP32_BOUNDS, report=None):
     return out
 
 
-def check_golden(g, key, t, rel=5e-5, stride=4):
+def check_golden(g, key, t, rel=1e-5, stride=4):
     """Tensor `t` against a golden entry written by tests/golden/make_golden.py::compact (sub-sampled data + fp64 sum and
     sum of squares of the full tensor)."""
     data, shape, stats = g[key + "/data"], tuple(g[key + "/shape"]), g[key + "/stats"]

@@ -136,7 +136,7 @@ def test_deconv_rewrite_is_exact():
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("compute", [N.F32, N.BF16])
+@pytest.mark.parametrize("compute", [N.F32, N.F16])
 def test_weight_packing_layout(compute):
     """[chunk][tap][Np][64 B]; chunks never straddle segments; zero padded."""
     torch.manual_seed(1)
@@ -155,8 +155,8 @@ def test_weight_packing_layout(compute):
         arr = host.view(np.float32).reshape(nch, 9, 32, 16)
         ref = w.numpy()
     else:
-        arr = (host.view(np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(nch, 9, 32, 32)
-        ref = w.to(torch.bfloat16).float().numpy()
+        arr = host.view(np.float16).astype(np.float32).reshape(nch, 9, 32, 32)
+        ref = w.to(torch.float16).float().numpy()
     chunk, cbase = 0, 0
     for c in segs:
         for j in range(-(-c // kce)):

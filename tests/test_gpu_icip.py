@@ -71,15 +71,15 @@ def test_icip_fp32_matches_oracle_and_reference_bitstream(icip_oracle, size):
         ops.set_precision("fp32")
 
 
-def test_icip_roundtrip_properties_large_and_bf16():
+def test_icip_roundtrip_properties_large_and_f16():
     """768x1024 (latent 48x64, 10 slices x 32 channels): encode -> decode round trip reproduces the encoder's latents bit
-    for bit, decoding is deterministic, bf16 mode stays within 1 % bytes and 0.05 dB (PSNR against the source) of fp32 mode."""
+    for bit, decoding is deterministic, f16 mode stays within 1 % bytes and 0.05 dB (PSNR against the source) of fp32 mode."""
     from deepsvc_amd import ops, synth
     H, W = 768, 1024
     x = synth.make_frames(H, W, 1, seed=11)[0].to(DEV)
     res = {}
     try:
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "f16"):
             m = _make(prec)
             for rep in range(2):                  # second pass runs on captured HIP graphs
                 enc = m.compress(x)
@@ -95,14 +95,14 @@ def test_icip_roundtrip_properties_large_and_bf16():
             n = len(enc["strings"][0][0]) + len(enc["strings"][1][0])
             res[prec] = (n, d1.float().cpu())
             assert tuple(enc["shape"]) == (H // 64, W // 64) and n > 1000
-        (nf, xf), (nb, xb) = res["fp32"], res["bf16"]
+        (nf, xf), (nb, xb) = res["fp32"], res["f16"]
         xc = x.float().cpu()
         pf, pb = psnr(xf, xc), psnr(xb, xc)
-        print(f"icip {H}x{W}: fp32 {nf} B, bf16 {nb} B ({100.0 * (nb - nf) / nf:+.3f} %), PSNR vs source fp32 {pf:.4f} / bf16 {pb:.4f} dB, "
-              f"PSNR(bf16, fp32) {psnr(xb, xf):.1f} dB")
+        print(f"icip {H}x{W}: fp32 {nf} B, f16 {nb} B ({100.0 * (nb - nf) / nf:+.3f} %), PSNR vs source fp32 {pf:.4f} / f16 {pb:.4f} dB, "
+              f"PSNR(f16, fp32) {psnr(xb, xf):.1f} dB")
         assert abs(nb - nf) <= 0.01 * nf                 # north-star tolerances: 1 % bytes, 0.05 dB
         assert abs(pb - pf) <= 0.05
-        assert psnr(xb, xf) > 30                         # 13 untrained 192-channel synthesis layers amplify bf16 rounding
+        assert psnr(xb, xf) > 30                         # 13 untrained 192-channel synthesis layers amplify f16 rounding
     finally:
         ops.set_precision("fp32")
 
@@ -111,7 +111,7 @@ def test_gop_with_intra_coded_key_frame():
     """BASELINE.json config 3 plumbing on the GPU: I-frame codec for the key frame, its reconstruction as the reference
     of the P-frame chain (harness.code_gop(..., i_model=...), test_video.py:296-312)."""
     from deepsvc_amd import harness, ops, synth
-    ops.set_precision("bf16")
+    ops.set_precision("f16")
     try:
         i_model = synth.make_icodec("W0"); i_model.update(force=True); i_model = i_model.to(DEV)
         p_model = synth.make_model("W0"); p_model.update(force=True); p_model = p_model.to(DEV)
@@ -134,7 +134,7 @@ def test_config3_gop12_four_rate_points():
     lambda in {256, 512, 1024, 2048}: synth.RATE_GAINS).  Properties the domain offers without the reference: every frame
     decodes, the rate grows with lambda for the I-frame and for the P-frames, and so does the key frame's PSNR."""
     from deepsvc_amd import harness, ops, synth
-    ops.set_precision("bf16")
+    ops.set_precision("f16")
     try:
         size, gop = 192, 12
         frames = [f.to(DEV) for f in synth.make_frames(size, size, gop)]

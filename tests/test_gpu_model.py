@@ -141,10 +141,10 @@ def test_full_size_1080p_roundtrip_properties(oracle_w0):
       * encode -> decode round trip: the decoder's latents y_hat (both codecs) are bit-identical to the encoder's;
       * determinism / idempotence: decoding the same strings twice gives bit-identical frames and features;
       * a second, chained P-frame (feature and reference from the decoder) behaves the same;
-      * bf16 mode stays inside the north-star tolerance of fp32 mode on the same inputs: |d bytes| <= 1 %, |d PSNR| <= 0.05 dB,
-        and the UN-CLAMPED reconstruction and the decoded 64-channel feature of bf16 mode are within the stated relative L2
-        of fp32 mode's (tests/parity_util.BF16_BOUNDS) -- the decoded frames are real pictures (< 1 % of pixels clamp), so
-        these numbers measure bf16, not the clamp."""
+      * f16 mode stays inside the north-star tolerance of fp32 mode on the same inputs: |d bytes| <= 1 %, |d PSNR| <= 0.05 dB,
+        and the UN-CLAMPED reconstruction and the decoded 64-channel feature of f16 mode are within the stated relative L2
+        of fp32 mode's (tests/parity_util.F16_BOUNDS) -- the decoded frames are real pictures (< 1 % of pixels clamp), so
+        these numbers measure f16, not the clamp."""
     from deepsvc_amd import ops, synth
     from deepsvc_amd.modules import pad
 
@@ -186,14 +186,14 @@ def test_full_size_1080p_roundtrip_properties(oracle_w0):
             ops.set_precision("fp32")
 
     import parity_util as PU
-    a, b = run("fp32"), run("bf16")
+    a, b = run("fp32"), run("f16")
     for t, ((na, ra, fa, pa), (nb, rb, fb, pb)) in enumerate(zip(a, b), 1):
         e_rec, e_fea = PU.rel_l2(rb, ra), PU.rel_l2(fb, fa)
-        print(f"1080p frame {t}: fp32 {na} B / {pa:.3f} dB, bf16 {nb} B / {pb:.3f} dB ({100.0 * (nb - na) / na:+.3f} %, {pb - pa:+.4f} dB); "
-              f"bf16 vs fp32 rel-L2: un-clamped recon {e_rec:.2e}, feature {e_fea:.2e}; PSNR(bf16 recon, fp32 recon) {PU.psnr(rb, ra):.1f} dB")
-        assert abs(nb - na) <= 0.01 * na, f"frame {t}: bf16 {nb} B vs fp32 {na} B"
-        assert abs(pb - pa) <= 0.05, f"frame {t}: PSNR bf16 {pb:.4f} vs fp32 {pa:.4f} dB"
-        assert e_rec <= PU.BF16_BOUNDS["recon"] and e_fea <= PU.BF16_BOUNDS["feature"]
+        print(f"1080p frame {t}: fp32 {na} B / {pa:.3f} dB, f16 {nb} B / {pb:.3f} dB ({100.0 * (nb - na) / na:+.3f} %, {pb - pa:+.4f} dB); "
+              f"f16 vs fp32 rel-L2: un-clamped recon {e_rec:.2e}, feature {e_fea:.2e}; PSNR(f16 recon, fp32 recon) {PU.psnr(rb, ra):.1f} dB")
+        assert abs(nb - na) <= 0.01 * na, f"frame {t}: f16 {nb} B vs fp32 {na} B"
+        assert abs(pb - pa) <= 0.05, f"frame {t}: PSNR f16 {pb:.4f} vs fp32 {pa:.4f} dB"
+        assert e_rec <= PU.F16_BOUNDS["recon"] and e_fea <= PU.F16_BOUNDS["feature"]
         assert pa > 15.0
 
 
@@ -215,13 +215,13 @@ def test_frame_container_round_trip_on_gpu(model):
     assert torch.equal(a[1], b[1]) and torch.equal(a[0].float(), b[0].float())
 
 
-def test_4k_whole_frame_round_trip_bf16():
-    """BASELINE.json config 5 size (3840x2160 -> padded 2176x3840) as a whole frame on one GPU in bf16 mode (DESIGN.md
+def test_4k_whole_frame_round_trip_f16():
+    """BASELINE.json config 5 size (3840x2160 -> padded 2176x3840) as a whole frame on one GPU in f16 mode (DESIGN.md
     section 6: spatial tiling is not result-preserving, so 4K runs un-tiled): the encode -> decode round trip holds
     (decoder latents == encoder latents), decoding is deterministic, every buffer stays under the 2 GiB extent limit."""
     from deepsvc_amd import ops, synth
     from deepsvc_amd.modules import pad
-    ops.set_precision("bf16")
+    ops.set_precision("f16")
     try:
         m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
         frames = [pad(f.to(DEV), 64) for f in synth.make_frames(2160, 3840, 2, seed=3)]
@@ -249,7 +249,7 @@ def test_gop_lanes_match_sequential_coding():
     """harness.code_gops_in_lanes (throughput mode: independent GOPs on concurrent lanes of one GPU, each with its own model
     instance / stream / thread) returns exactly the rows of coding the GOPs one after the other."""
     from deepsvc_amd import harness, ops, synth
-    ops.set_precision("bf16")
+    ops.set_precision("f16")
     try:
         size, n_gops = 256, 3
         gops = []

@@ -1,6 +1,6 @@
 """GPU parity of every HIP op, called through the C ABI (deepsvc_amd.ops), against plain PyTorch-CPU fp32
 (or the oracle's restatement) on the same seeded inputs.  Tolerances: fp32 MFMA path 1e-4 relative to the
-output scale; bf16 MFMA path is compared with a reference fed the same bf16-rounded operands (5e-3)."""
+output scale; f16 MFMA path is compared with a reference fed the same f16-rounded operands (5e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -47,7 +47,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("compute", ["fp32", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{'+'.join(map(str, c[0]))}to{c[1]}_k{c[2]}s{c[3]}_{c[4]}x{c[5]}")
 def test_conv_plain(case, compute):
     from deepsvc_amd import ops
@@ -62,8 +62,8 @@ def test_conv_plain(case, compute):
     finally:
         ops.set_precision("fp32")
     x, w = torch.cat(xs, 1), m.weight.detach().cpu()
-    if compute == "bf16":
-        x, w = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    if compute == "f16":
+        x, w = x.to(torch.float16).float(), w.to(torch.float16).float()
     want = F.conv2d(x, w, m.bias.detach().cpu(), stride=s, padding=k // 2)
     tol = 2e-4 if compute == "fp32" else 5e-3
     report_close(f"conv {case} {compute}", got, want, tol, tol * float(want.abs().max()))
@@ -81,7 +81,7 @@ def test_conv_epilogue_activations(act):
     report_close(f"epilogue act={act}", got, want, 2e-4, 2e-4)
 
 
-def test_conv_slices_shuffle_and_bf16_storage():
+def test_conv_slices_shuffle_and_f16_storage():
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d, Deconv5x5s2, _SubpelConv
     torch.manual_seed(5)
@@ -107,28 +107,28 @@ def test_conv_slices_shuffle_and_bf16_storage():
     x = torch.randn(1, 10, 6, 9)
     want = F.conv_transpose2d(x, d.weight.cpu(), d.bias.cpu(), stride=2, padding=2, output_padding=1)
     report_close("deconv", d.run(_act(x)).nchw().cpu(), want, 2e-4, 2e-4)
-    # bf16 activation storage in and out
+    # f16 activation storage in and out
     x = torch.randn(1, 32, 10, 34)
     mm = Conv2d(32, 32, 3, 1, 1).to(DEV)
     res = torch.randn(1, 32, 10, 34)
-    got = mm.run(_act(x, torch.bfloat16), res1=_act(res, torch.bfloat16), out_dtype=torch.bfloat16)
-    assert got.dtype == torch.bfloat16
-    want = F.conv2d(x.to(torch.bfloat16).float(), mm.weight.cpu(), mm.bias.cpu(), padding=1) + res.to(torch.bfloat16).float()
-    report_close("bf16 storage", got.nchw().cpu(), want, 1e-2, 1e-2)
+    got = mm.run(_act(x, torch.float16), res1=_act(res, torch.float16), out_dtype=torch.float16)
+    assert got.dtype == torch.float16
+    want = F.conv2d(x.to(torch.float16).float(), mm.weight.cpu(), mm.bias.cpu(), padding=1) + res.to(torch.float16).float()
+    report_close("f16 storage", got.nchw().cpu(), want, 1e-2, 1e-2)
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 250, 1100), (64, 32, 256, 1024), (64, 3, 264, 1000), (32, 64, 250, 1090), (32, 3, 256, 1056), (3, 64, 250, 1100)])
 def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
-    """Large-image bf16 3x3 convs take the persistent weight-stationary kernel (csrc/conv3x3_ws.hip):
-    ragged right/bottom tiles, the fused pre-activation, activation, both residuals and bf16 stores."""
+    """Large-image f16 3x3 convs take the persistent weight-stationary kernel (csrc/conv3x3_ws.hip):
+    ragged right/bottom tiles, the fused pre-activation, activation, both residuals and f16 stores."""
     from deepsvc_amd import _native as N, ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(cin * 100 + cout)
-    ops.set_precision("bf16")
+    ops.set_precision("f16")
     try:
         m = Conv2d(cin, cout, 3, 1, 1).to(DEV)
         x, r1, r2 = torch.randn(1, cin, H, W), torch.randn(1, cout, H, W), torch.randn(1, cout, H, W)
-        bf = torch.bfloat16
+        bf = torch.float16
         plain = m.run(_act(x, bf), out_dtype=torch.float32).nchw().cpu()
         fused = m.run(_act(x, bf), pre_act=N.ACT_LRELU, act=N.ACT_LRELU, slope=0.01, res1=_act(r1, bf), res2=_act(r2, bf),
                       out_dtype=bf).nchw().cpu()
@@ -157,15 +157,15 @@ def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
     ((32,), 64, 1, 256, 1024, 0, 0, 0),
 ])
 def test_conv3x3_pingpong_kernel(segs, cout, B, H, W, pre, act, nres):
-    """The 64-channel bf16 ResBlock family takes the two-group phase-skewed kernel (csrc/conv3x3_pp.hip): every
-    fused variant it accepts against torch on the same bf16-rounded operands, plus agreement with the
+    """The 64-channel f16 ResBlock family takes the two-group phase-skewed kernel (csrc/conv3x3_pp.hip): every
+    fused variant it accepts against torch on the same f16-rounded operands, plus agreement with the
     weight-stationary kernel it replaces (DSVC_NO_PP is read once per process, so that leg uses an fp32-output
     launch, which the ping-pong kernel does not take)."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) + cout + H)
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     try:
         m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
         xs = [torch.randn(B, c, H, W) for c in segs]
@@ -197,16 +197,16 @@ def test_conv3x3_pingpong_kernel(segs, cout, B, H, W, pre, act, nres):
     (64, 3, 250, 1100, 0, None, "f32"),      # frame heads
     (64, 2, 251, 1043, 0, "f32", "f32"),     # flow head + fp32 residual
     (32, 3, 264, 1000, 0, None, "f32"),      # single-chunk input
-    (64, 8, 256, 1056, 1, "bf16", "bf16"),   # 8 channels, bf16 out + bf16 residual
+    (64, 8, 256, 1056, 1, "f16", "f16"),   # 8 channels, f16 out + f16 residual
 ])
 def test_conv3x3_pingpong_narrow_head(cin, cout, H, W, act, res, out_dt):
-    """Narrow output heads (Cout <= 8) on the ping-pong kernel: one N-tile, element-wise fp32/bf16 stores."""
+    """Narrow output heads (Cout <= 8) on the ping-pong kernel: one N-tile, element-wise fp32/f16 stores."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(cin + cout + W)
-    bf = torch.bfloat16
-    dts = {"f32": torch.float32, "bf16": bf}
-    ops.set_precision("bf16")
+    bf = torch.float16
+    dts = {"f32": torch.float32, "f16": bf}
+    ops.set_precision("f16")
     try:
         m = Conv2d(cin, cout, 3, 1, 1).to(DEV)
         x = torch.randn(1, cin, H, W)
@@ -225,33 +225,32 @@ def test_conv3x3_pingpong_narrow_head(cin, cout, H, W, act, res, out_dt):
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
     want = _torch_act(F.conv2d(x.to(bf).float(), w, b, padding=1), act, 0.05)
     if res:
-        want = want + (r.to(bf).float() if res == "bf16" else r)
-    rt = 2e-2 if out_dt == "bf16" else 5e-3
+        want = want + (r.to(bf).float() if res == "f16" else r)
+    rt = 2e-2 if out_dt == "f16" else 5e-3
     report_close("head vs torch", got, want, rt, rt * float(want.abs().max()))
     report_close("head vs ws", got, other, rt, rt * float(want.abs().max()))
 
 
 @pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,act,res,out_dt", [
-    ((96, 48), ("f32", "f32"), 96, 1, 68, 120, 3, None, "bf16"),          # cc_mean/cc_scale first layer (GELU)
-    ((96,), ("bf16",), 64, 1, 68, 120, 3, None, "bf16"),                  # hidden layers
-    ((64,), ("bf16",), 32, 1, 17, 30, 3, None, "bf16"),
-    ((32,), ("bf16",), 12, 1, 68, 120, 0, None, "f32"),                   # last layer: 12 channels, fp32 out
-    ((96, 48, 16), ("f32", "f32", "bf16"), 96, 1, 34, 60, 3, None, "bf16"),   # three mixed segments, short chunks
+    ((96, 48), ("f32", "f32"), 96, 1, 68, 120, 3, None, "f16"),          # cc_mean/cc_scale first layer (GELU)
+    ((96,), ("f16",), 64, 1, 68, 120, 3, None, "f16"),                  # hidden layers
+    ((64,), ("f16",), 32, 1, 17, 30, 3, None, "f16"),
+    ((32,), ("f16",), 12, 1, 68, 120, 0, None, "f32"),                   # last layer: 12 channels, fp32 out
+    ((96, 48, 16), ("f32", "f32", "f16"), 96, 1, 34, 60, 3, None, "f16"),   # three mixed segments, short chunks
     ((96, 8), ("f32", "f32"), 48, 2, 9, 33, 5, "f32", "f32"),             # lrp tail: 0.5*tanh + fp32 residual, batch 2
-    ((64,), ("bf16",), 224, 1, 5, 7, 1, "bf16", "bf16"),                  # 7 N-tiles, tiny image, bf16 residual
+    ((64,), ("f16",), 224, 1, 5, 7, 1, "f16", "f16"),                  # 7 N-tiles, tiny image, f16 residual
     ((64, 32, 8), ("f32", "f32", "f32"), 8, 1, 68, 120, 4, None, "f32"),  # sigmoid, 8 channels
 ])
-def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res, out_dt):
-    """Small-image bf16 3x3 convs (the slice-scan nets) can take the barrier-free kernel whose MFMA fragments are loaded
-    straight from global memory (csrc/conv3x3_direct.hip): mixed fp32/bf16 segments, short channel chunks, ragged
-    row ends, every activation, residual and output type it accepts -- against torch on bf16-rounded operands."""
+def test_conv3x3_small_image_scan_net_shapes(segs, seg_dt, cout, B, H, W, act, res, out_dt):
+    """Small-image f16 3x3 convs in the shapes of the slice-scan nets: mixed fp32/f16 segments (fp32 latents converted while
+    staged), short channel chunks, ragged row ends, every activation, residual and output type -- against torch on
+    f16-rounded operands."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) * 7 + cout + W)
-    bf = torch.bfloat16
-    dts = {"f32": torch.float32, "bf16": bf}
-    ops.set_precision("bf16")
-    was = ops.set_option("direct", 1)            # opt-in kernel (slower end to end on the scan nets so far)
+    bf = torch.float16
+    dts = {"f32": torch.float32, "f16": bf}
+    ops.set_precision("f16")
     try:
         m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
         xs = [torch.randn(B, c, H, W) for c in segs]
@@ -262,19 +261,18 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
             kw["res1"] = _act(r, dts[res])
         got = m.run(ins if len(ins) > 1 else ins[0], out_dtype=dts[out_dt], **kw).nchw().float().cpu()
     finally:
-        ops.set_option("direct", was)
         ops.set_precision("fp32")
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
     xb = torch.cat([x.to(bf).float() for x in xs], 1)
     want = _torch_act(F.conv2d(xb, w, b, padding=1), act, 0.05)
     if res:
-        want = want + (r.to(bf).float() if res == "bf16" else r)
-    tol = (2e-2 if out_dt == "bf16" else 5e-3) * float(want.abs().max())
-    report_close("direct vs torch", got, want, 2e-2 if out_dt == "bf16" else 5e-3, tol)
+        want = want + (r.to(bf).float() if res == "f16" else r)
+    tol = (2e-2 if out_dt == "f16" else 5e-3) * float(want.abs().max())
+    report_close("small conv vs torch", got, want, 2e-2 if out_dt == "f16" else 5e-3, tol)
 
 
 @pytest.mark.parametrize("segs,cout,k,stride,B,H,W,pre,act,res", [
-    ((96,), 96, 3, 1, 1, 200, 330, 0, 2, True),          # three N-tiles, LeakyReLU, bf16 residual, ragged right edge (330 = 10*32 + 10)
+    ((96,), 96, 3, 1, 1, 200, 330, 0, 2, True),          # three N-tiles, LeakyReLU, f16 residual, ragged right edge (330 = 10*32 + 10)
     ((64, 64), 64, 3, 1, 2, 100, 200, 0, 0, False),      # two segments, batch 2, no activation
     ((128,), 128, 3, 1, 1, 162, 320, 1, 1, True),        # four N-tiles (k-step pipeline), ReLU in and out, ragged bottom edge
     ((32,), 64, 7, 1, 1, 120, 250, 0, 1, False),         # 7x7: tap groups of one kernel row
@@ -286,12 +284,12 @@ def test_conv3x3_direct_small_image_kernel(segs, seg_dt, cout, B, H, W, act, res
 def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, H, W, pre, act, res):
     """The generic kernel's LDS-free epilogue (MFMA operands swapped, one 32-lane swap, two 16-byte stores per lane and
     32-channel tile) against the slab epilogue of the same kernel: same accumulation order, same arithmetic -> equal results;
-    and against torch on bf16-rounded operands."""
+    and against torch on f16-rounded operands."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) + cout + W)
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     was_s, was_t = ops.set_option("specialised", 0), ops.set_option("tall_min_tiles", 1 if sum(segs) == 128 and cout == 64 else 1 << 30)
     try:
         m = Conv2d(sum(segs), cout, k, stride, k // 2).to(DEV)
@@ -332,12 +330,12 @@ def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, 
 ])
 def test_conv_wide_output_variants(segs, cout, k, stride, H, W, act, res):
     """Images large enough that the generic kernel keeps 3-4 N-tiles (96-128 output channels) per workgroup: the variants
-    with register-prefetched weights and (for 128 channels) k-step fragment pipelining -- against torch on bf16-rounded operands."""
+    with register-prefetched weights and (for 128 channels) k-step fragment pipelining -- against torch on f16-rounded operands."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) + cout + W)
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     try:
         m = Conv2d(sum(segs), cout, k, stride, k // 2).to(DEV)
         xs = [torch.randn(1, c, H, W) for c in segs]
@@ -359,20 +357,20 @@ def test_conv_wide_output_variants(segs, cout, k, stride, H, W, act, res):
 
 @pytest.mark.parametrize("segs,cout,k,B,H,W,pre,act,res", [
     ((64, 64), 64, 3, 1, 70, 100, 0, 2, False),          # two segments, ragged rows and columns (70 = 4*16 + 6)
-    ((32, 32), 64, 3, 2, 33, 45, 2, 2, True),            # batch 2, LeakyReLU in and out, bf16 residual
+    ((32, 32), 64, 3, 2, 33, 45, 2, 2, True),            # batch 2, LeakyReLU in and out, f16 residual
     ((32,), 64, 5, 1, 50, 64, 0, 1, False),              # 5x5: tap groups of one kernel row
     ((64, 8), 128, 3, 1, 48, 96, 0, 0, False),           # 128 output channels = two groups of 64
     ((64, 32), 64, 3, 2, 25, 33, 1, 0, False),           # three chunks over two segments, batch 2, ReLU on the way in
 ])
 def test_conv_tall_tile_variant(segs, cout, k, B, H, W, pre, act, res):
-    """The generic kernel's 16x32-pixel tile variant (bf16, stride 1, 64 output channels per group; picked from
+    """The generic kernel's 16x32-pixel tile variant (f16, stride 1, 64 output channels per group; picked from
     `tall_min_tiles` tiles on) against the 8x32 tiling of the same kernel -- identical accumulation order per output,
-    so bit-identical results -- and against torch on bf16-rounded operands."""
+    so bit-identical results -- and against torch on f16-rounded operands."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) + cout + W)
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     was_s, was_t, was_p = ops.set_option("specialised", 0), ops.set_option("tall_min_tiles", 1), ops.set_option("patch_prefetch", 0)
     try:
         m = Conv2d(sum(segs), cout, k, 1, k // 2).to(DEV)
@@ -400,19 +398,19 @@ def test_conv_tall_tile_variant(segs, cout, k, B, H, W, pre, act, res):
 @pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,pre,act", [
     ((96, 48), ("f32", "f32"), 96, 1, 68, 120, 0, 3),                 # cc_mean/cc_scale first layer
     ((96, 36), ("f32", "f32"), 96, 1, 68, 120, 0, 3),                 # 36 = 32 + a half-filled quarter (C % 8 == 4)
-    ((64, 12, 8), ("f32", "f32", "bf16"), 64, 2, 33, 70, 2, 2),       # mixed storage, short chunks, LeakyReLU on the way in
+    ((64, 12, 8), ("f32", "f32", "f16"), 64, 2, 33, 70, 2, 2),       # mixed storage, short chunks, LeakyReLU on the way in
     ((4,), ("f32",), 32, 1, 40, 50, 1, 0),                            # a single half quarter
 ])
 def test_conv_fp32_storage_converted_while_staged(segs, seg_dt, cout, B, H, W, pre, act):
-    """bf16 compute over fp32 storage (the slice scan's fp32 latents): the general kernel converts while staging --
-    two batched 16-B loads per 8-channel quarter, RNE to bf16 -- instead of the per-element path.  Against torch on
-    bf16-rounded operands, including segments whose channel count is 4 mod 8 and a fused leading activation."""
+    """f16 compute over fp32 storage (the slice scan's fp32 latents): the general kernel converts while staging --
+    two batched 16-B loads per 8-channel quarter, RNE to f16 -- instead of the per-element path.  Against torch on
+    f16-rounded operands, including segments whose channel count is 4 mod 8 and a fused leading activation."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) * 3 + cout + W)
-    bf = torch.bfloat16
-    dts = {"f32": torch.float32, "bf16": bf}
-    ops.set_precision("bf16")
+    bf = torch.float16
+    dts = {"f32": torch.float32, "f16": bf}
+    ops.set_precision("f16")
     try:
         m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
         xs = [torch.randn(B, c, H, W) for c in segs]
@@ -421,7 +419,7 @@ def test_conv_fp32_storage_converted_while_staged(segs, seg_dt, cout, B, H, W, p
     finally:
         ops.set_precision("fp32")
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
-    xb = torch.cat([_torch_act(x.to(bf).float() if t == "bf16" else x, pre, 0.05).to(bf).float() for x, t in zip(xs, seg_dt)], 1)
+    xb = torch.cat([_torch_act(x.to(bf).float() if t == "f16" else x, pre, 0.05).to(bf).float() for x, t in zip(xs, seg_dt)], 1)
     want = _torch_act(F.conv2d(xb, w, b, padding=1), act, 0.05)
     report_close("converted staging vs torch", got, want, 5e-3, 5e-3 * float(want.abs().max()))
 
@@ -429,14 +427,14 @@ def test_conv_fp32_storage_converted_while_staged(segs, seg_dt, cout, B, H, W, p
 @pytest.mark.parametrize("segs,cout,B,H,W", [((8, 64, 8), 96, 1, 64, 96), ((8,), 64, 2, 128, 160), ((8, 64, 8), 96, 1, 272, 480),
                                              ((16, 8), 192, 1, 34, 62), ((8,), 192, 1, 64, 64)])
 def test_conv5x5s2_space_to_depth_view(segs, cout, B, H, W):
-    """bf16 conv5x5/s2 with bf16 inputs runs as a 3x3/s1 conv over the space-to-depth view (include/dsvc.h: s2d; weights
-    remapped by ops.s2d_weights): against torch's stride-2 conv on the same bf16-rounded operands, and against the
+    """f16 conv5x5/s2 with f16 inputs runs as a 3x3/s1 conv over the space-to-depth view (include/dsvc.h: s2d; weights
+    remapped by ops.s2d_weights): against torch's stride-2 conv on the same f16-rounded operands, and against the
     direct 5x5/s2 execution of the same layer."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) + cout)
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     try:
         m = Conv2d(sum(segs), cout, 5, 2, 2).to(DEV)
         xs = [torch.randn(B, c, H, W) for c in segs]
@@ -461,12 +459,12 @@ def test_conv5x5s2_space_to_depth_view(segs, cout, B, H, W):
 @pytest.mark.parametrize("B,H,W,slope", [(1, 256, 1024, 0.01), (1, 250, 1100, 0.01), (2, 130, 1000, 0.0)])
 def test_res_bottleneck_fused_tail(B, H, W, slope):
     """ResBottleneckBlock (modules.py:173-189) with conv2 -> act -> conv3 -> + x fused into one launch of the two-group 3x3
-    kernel (include/dsvc.h: post_weight) against the three-launch execution and against torch on bf16-rounded operands."""
+    kernel (include/dsvc.h: post_weight) against the three-launch execution and against torch on f16-rounded operands."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import ResBottleneckBlock
     torch.manual_seed(H + W)
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     try:
         m = ResBottleneckBlock(64, slope=slope).to(DEV)
         x = torch.randn(B, 64, H, W)
@@ -499,8 +497,8 @@ def test_conv1x1_gated_two_segment(segs, cout):
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(sum(segs) + cout)
     H, W = 250, 333
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     try:
         m = Conv2d(sum(segs), cout, 1, 1, 0).to(DEV)
         xs = [torch.randn(1, c, H, W) for c in segs]
@@ -517,14 +515,14 @@ def test_conv1x1_gated_two_segment(segs, cout):
 @pytest.mark.parametrize("cin,cout,act,res", [(64, 64, 2, True), (96, 96, 0, True), (96, 96, 2, False), (128, 128, 1, True),
                                               (32, 64, 0, False), (64, 40, 2, True)])
 def test_conv1x1_register_epilogue(cin, cout, act, res):
-    """bf16-out 1x1 convs with activation in {none, ReLU, LeakyReLU} and at most one bf16 residual (conv1 / conv3 of the
+    """f16-out 1x1 convs with activation in {none, ReLU, LeakyReLU} and at most one f16 residual (conv1 / conv3 of the
     ResBottleneck blocks) take the register epilogue of csrc/conv1x1.hip: ragged pixel count, partial last N-tile."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(cin * 3 + cout)
     H, W = 250, 333              # 83250 pixels: not a multiple of 32
-    bf = torch.bfloat16
-    ops.set_precision("bf16")
+    bf = torch.float16
+    ops.set_precision("f16")
     try:
         m = Conv2d(cin, cout, 1, 1, 0).to(DEV)
         x, r1 = torch.randn(1, cin, H, W), torch.randn(1, cout, H, W)
@@ -546,18 +544,18 @@ def test_conv1x1_register_epilogue(cin, cout, act, res):
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
 def test_conv1x1_streaming_kernel(cin, cout):
-    """Large bf16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,
+    """Large f16 pointwise convs take the LDS-free streaming kernel (csrc/conv1x1.hip): ragged pixel count,
     activation, gated residual + second residual."""
     from deepsvc_amd import _native as N, ops
     from deepsvc_amd.modules import Conv2d
     torch.manual_seed(cin + cout)
     H, W = 250, 333              # 83250 pixels: not a multiple of 32
-    ops.set_precision("bf16")
+    ops.set_precision("f16")
     try:
         m = Conv2d(cin, cout, 1, 1, 0).to(DEV)
         x, r1, r2 = torch.randn(1, cin, H, W), torch.randn(1, cout, H, W), torch.randn(1, cout, H, W)
         gate = torch.rand(1, cout)
-        bf = torch.bfloat16
+        bf = torch.float16
         plain = m.run(_act(x, bf), act=N.ACT_LRELU, slope=0.01, out_dtype=torch.float32).nchw().cpu()
         fused = m.run(_act(x, bf), res1=_act(r1, bf), gate=gate.to(DEV), res2=_act(r2), out_dtype=bf).nchw().cpu()
     finally:
@@ -592,22 +590,22 @@ def test_resampling_and_layout_ops():
     report_close("avgpool", ops.pool2x2(_act(x), "avg").nchw().cpu(), F.avg_pool2d(x, 2, 2), 1e-6, 1e-6)
     x = torch.randn(2, 32, 6, 10)
     report_close("maxpool", ops.pool2x2(_act(x), "max").nchw().cpu(), F.max_pool2d(x, 2, 2), 0, 0)
-    for C, dt in ((64, torch.bfloat16), (16, torch.bfloat16), (8, torch.float32), (64, torch.float32)):     # 16 bytes per thread
+    for C, dt in ((64, torch.float16), (16, torch.float16), (8, torch.float32), (64, torch.float32)):     # 16 bytes per thread
         x = torch.randn(2, C, 6, 10).to(dt).float()
         for mode, ref in (("avg", F.avg_pool2d), ("max", F.max_pool2d)):
-            report_close(f"{mode}pool vec {C} {dt}", ops.pool2x2(_act(x, dt), mode).nchw().float().cpu(), ref(x, 2, 2).to(dt).float(), 1e-2 if dt == torch.bfloat16 else 1e-6, 2e-2 if dt == torch.bfloat16 else 1e-6)
+            report_close(f"{mode}pool vec {C} {dt}", ops.pool2x2(_act(x, dt), mode).nchw().float().cpu(), ref(x, 2, 2).to(dt).float(), 1e-2 if dt == torch.float16 else 1e-6, 2e-2 if dt == torch.float16 else 1e-6)
     x = torch.randn(2, 64, 5, 6)
     report_close("pixel_shuffle4", ops.pixel_shuffle_nchw(x.to(DEV), 4, dtype=torch.float32).nchw().cpu(), F.pixel_shuffle(x, 4), 0, 0)
     for shape, r in (((2, 256, 5, 70), 4), ((1, 32, 7, 9), 2), ((1, 128, 3, 130), 4)):      # Co % 8 == 0: one thread per pixel x 8 channels
         x = torch.randn(*shape)
         report_close(f"pixel_shuffle{r} vec8 f32", ops.pixel_shuffle_nchw(x.to(DEV), r, dtype=torch.float32).nchw().cpu(), F.pixel_shuffle(x, r), 0, 0)
-        report_close(f"pixel_shuffle{r} vec8 bf16", ops.pixel_shuffle_nchw(x.to(DEV), r, dtype=torch.bfloat16).nchw().cpu(),
-                     F.pixel_shuffle(x, r).to(torch.bfloat16).float(), 0, 0)
+        report_close(f"pixel_shuffle{r} vec8 f16", ops.pixel_shuffle_nchw(x.to(DEV), r, dtype=torch.float16).nchw().cpu(),
+                     F.pixel_shuffle(x, r).to(torch.float16).float(), 0, 0)
     x = torch.randn(2, 37, 9, 11)       # NCHW-contiguous input goes through the transpose kernel
     a = ops.to_act(x.to(DEV))
     assert torch.equal(a.buf.cpu(), x.permute(0, 2, 3, 1).contiguous())
-    b16 = ops.to_act(x.to(DEV), torch.bfloat16)
-    assert torch.equal(b16.nchw().cpu(), x.to(torch.bfloat16).float())
+    b16 = ops.to_act(x.to(DEV), torch.float16)
+    assert torch.equal(b16.nchw().cpu(), x.to(torch.float16).float())
     xc = x.to(DEV).contiguous(memory_format=torch.channels_last)   # channels_last input is taken zero-copy
     assert ops.to_act(xc).buf.data_ptr() == xc.data_ptr()
 
@@ -623,10 +621,10 @@ def test_pointwise_and_reductions():
     report_close("blend2", ops.eltwise(N.EW_BLEND2, A, B, d=Wt).nchw().cpu(), w * a + (1 - w) * b, 1e-6, 1e-6)
     report_close("blend3", ops.eltwise(N.EW_BLEND3, A, B, C, Wt, V).nchw().cpu(), w * a + v * b + (1 - w - v) * c, 1e-6, 1e-6)
     report_close("clamp", ops.eltwise(N.EW_CLAMP01, A).nchw().cpu(), a.clamp(0, 1), 0, 0)
-    # 8-channel vector path (C % 8 == 0), mixed fp32 / bf16 operands
+    # 8-channel vector path (C % 8 == 0), mixed fp32 / f16 operands
     a, b, c = (torch.randn(2, 16, 9, 10) for _ in range(3))
     w, v = torch.rand(2, 16, 9, 10), torch.rand(2, 16, 9, 10)
-    bf = torch.bfloat16
+    bf = torch.float16
     A, B, C, Wt, V = _act(a, bf), _act(b), _act(c, bf), _act(w), _act(v, bf)
     ab, cb, vb = a.to(bf).float(), c.to(bf).float(), v.to(bf).float()
     report_close("sub8", ops.eltwise(N.EW_SUB, A, B, out_dtype=torch.float32).nchw().cpu(), ab - b, 1e-6, 1e-6)

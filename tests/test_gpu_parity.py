@@ -5,7 +5,7 @@
   * the REFERENCE's own golden byte strings (tests/golden, produced by running the reference) decoded by the GPU decoder,
     checked against the reference's decoded tensors -- 64x64 (first + steady-state P-frame) and BASELINE.json config 1:
     one 256x256 septuplet, six chained P-frames, on both the decode and the encode side;
-  * bf16 mode: relative-L2 of feature / un-clamped recon against the fp32 oracle, rate and PSNR deltas;
+  * f16 mode: relative-L2 of feature / un-clamped recon against the fp32 oracle, rate and PSNR deltas;
   * mutation test: a zero decoder, a skipped UNet and one zeroed filter tap each turn the checks red.
 """
 import numpy as np
@@ -212,17 +212,17 @@ def test_parity_checks_catch_mutations(oracle_w0):
 
 
 # ------------------------------------------------------------------------------------------------------------
-# bf16 mode
+# f16 mode
 # ------------------------------------------------------------------------------------------------------------
-def test_bf16_mode_vs_fp32_oracle(oracle_w0):
-    """Fast mode (bf16 MFMA operands, bf16 activation storage, fp32 accumulation): same API; encoder/decoder stay in lock
+def test_f16_mode_vs_fp32_oracle(oracle_w0):
+    """Fast mode (f16 MFMA operands, f16 activation storage, fp32 accumulation): same API; encoder/decoder stay in lock
     step; un-clamped decoded tensors within the stated relative-L2 of the fp32 oracle over three chained P-frames at 128x128;
     rate within 1 %, PSNR within 0.05 dB (north_star tolerances)."""
     from deepsvc_amd import ops, synth
     from oracle.codec import strings_nbytes
     size = 128
     fr = synth.make_frames(size, size, 4)
-    m = _fresh_model("bf16")
+    m = _fresh_model("f16")
     try:
         ref_g, ref_o, feat_g, feat_o = fr[0].to(DEV), fr[0], None, None
         for t in (1, 2, 3):
@@ -233,11 +233,11 @@ def test_bf16_mode_vs_fp32_oracle(oracle_w0):
             assert torch.equal(dec_g[1], dec_g2[1])
             mv_o, res_o = oracle_w0.compress(ref_o, fr[t], sm, feat_o)
             dec_o, want, _ = _oracle_decode(oracle_w0, ref_o, mv_o, res_o, sm, feat_o)
-            PU.check_frame(f"128 f{t} bf16 vs fp32 oracle", got, want, PU.BF16_BOUNDS)
+            PU.check_frame(f"128 f{t} f16 vs fp32 oracle", got, want, PU.F16_BOUNDS)
             b_g, b_o = strings_nbytes(mv_g) + strings_nbytes(res_g), strings_nbytes(mv_o) + strings_nbytes(res_o)
             p_g, p_o = PU.psnr(dec_g[1].cpu(), fr[t]), PU.psnr(dec_o[1], fr[t])
-            print(f"[parity] bf16 f{t}: bytes {b_g} vs {b_o} ({100 * (b_g - b_o) / b_o:+.2f} %), PSNR {p_g:.4f} vs {p_o:.4f} dB, "
-                  f"PSNR(bf16 recon, fp32 recon) {PU.psnr(got['recon'], want['recon']):.1f} dB")
+            print(f"[parity] f16 f{t}: bytes {b_g} vs {b_o} ({100 * (b_g - b_o) / b_o:+.2f} %), PSNR {p_g:.4f} vs {p_o:.4f} dB, "
+                  f"PSNR(f16 recon, fp32 recon) {PU.psnr(got['recon'], want['recon']):.1f} dB")
             assert abs(b_g - b_o) <= 0.01 * b_o
             assert abs(p_g - p_o) <= 0.05
             # chain each side on its own decoded state, as a real encoder/decoder pair would

@@ -4,12 +4,12 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepsvc_amd import _native as N, ops
 from deepsvc_amd.modules import Conv2d
-ops.set_precision("bf16")
+ops.set_precision("f16")
 dev = "cuda:0"
 for H in (1088, 544):
     m = Conv2d(64, 64, 1, 1, 0).to(dev)
-    x = ops.Act(torch.randn((1, H, 1920, 64), device=dev).to(torch.bfloat16))
-    y = ops.new_act(1, H, 1920, 64, torch.bfloat16, dev)
+    x = ops.Act(torch.randn((1, H, 1920, 64), device=dev).to(torch.float16))
+    y = ops.new_act(1, H, 1920, 64, torch.float16, dev)
     for _ in range(4):
         m.run(x, y); m.run(y, x)
     torch.cuda.synchronize()

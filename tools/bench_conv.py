@@ -1,5 +1,5 @@
 """Micro-benchmark of the conv kernel on the shapes that dominate a 1080p P-frame.
-    python tools/bench_conv.py [--precision bf16|fp32] [--iters 20]
+    python tools/bench_conv.py [--precision f16|fp32] [--iters 20]
 Prints per-shape average launch time (HIP events on the launch stream) and achieved TFLOP/s."""
 import argparse
 import os
@@ -48,7 +48,7 @@ SHAPES += [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="f16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=int, default=-1, help="run only shape #i")
     args = ap.parse_args()
@@ -78,7 +78,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
         flop = 2.0 * Ho * Wo * cout * sum(segs) * k * k
-        es = 2 if st == torch.bfloat16 else 4
+        es = 2 if st == torch.float16 else 4
         gbytes = (H * W * sum(segs) * (4 if kw.get("f32in") else es) + Ho * Wo * cout * es * (2 if kw.get("res") else 1)) / 1e9
         print(f"{name:36s} {ms*1e3:9.1f} us  {flop/ms/1e9:8.1f} TFLOP/s  {gbytes/ms*1e3:7.0f} GB/s (algorithmic)", flush=True)
 

@@ -18,14 +18,14 @@ SHAPES = [  # (name, cin, cout, k, H, W, act, res)
     ("3x3 64->64 @1/8 lrelu", 64, 64, 3, 136, 240, N.ACT_LRELU, False),
 ]
 dev = "cuda:0"
-ops.set_precision("bf16")
+ops.set_precision("f16")
 NL = 20
 for name, cin, cout, k, H, W, act, res in SHAPES:
     torch.manual_seed(0)
     m = Conv2d(cin, cout, k, 1, k // 2).to(dev)
-    x = ops.Act(torch.randn((1, H, W, cin), device=dev).to(torch.bfloat16))
-    out = ops.new_act(1, H, W, cout, torch.bfloat16, dev)
-    r = ops.Act(torch.randn((1, H, W, cout), device=dev).to(torch.bfloat16)) if res else None
+    x = ops.Act(torch.randn((1, H, W, cin), device=dev).to(torch.float16))
+    out = ops.new_act(1, H, W, cout, torch.float16, dev)
+    r = ops.Act(torch.randn((1, H, W, cout), device=dev).to(torch.float16)) if res else None
     for _ in range(3):
         m.run(x, out, act=act, res1=r)
     torch.cuda.synchronize()

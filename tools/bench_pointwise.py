@@ -15,7 +15,7 @@ def timeit(name, fn, nbytes, n=20):
     print(f"{name:44s} {us:8.1f} us  {nbytes/us/1e3:7.0f} GB/s", flush=True)
 
 sm = torch.randn(1, 256, 272, 480, device=dev)
-out = ops.new_act(1, 1088, 1920, 16, torch.bfloat16, dev)
-timeit("pixel_shuffle4 [256,272,480] f32 -> bf16 NHWC", lambda: ops.pixel_shuffle_nchw(sm, 4, out=out), sm.numel() * 4 + out.buf.numel() * 2)
-x = ops.new_act(1, 1088, 1920, 64, torch.bfloat16, dev); x.buf.normal_()
-timeit("pool2x2 avg 64ch bf16 @1080p", lambda: ops.pool2x2(x, "avg"), x.buf.numel() * 2 * 1.25)
+out = ops.new_act(1, 1088, 1920, 16, torch.float16, dev)
+timeit("pixel_shuffle4 [256,272,480] f32 -> f16 NHWC", lambda: ops.pixel_shuffle_nchw(sm, 4, out=out), sm.numel() * 4 + out.buf.numel() * 2)
+x = ops.new_act(1, 1088, 1920, 64, torch.float16, dev); x.buf.normal_()
+timeit("pool2x2 avg 64ch f16 @1080p", lambda: ops.pool2x2(x, "avg"), x.buf.numel() * 2 * 1.25)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepsvc_amd import ops, synth  # noqa: E402
 from deepsvc_amd.modules import pad  # noqa: E402
 
-ops.set_precision("bf16")
+ops.set_precision("f16")
 dev = "cuda:0"
 m = synth.make_icodec("W0"); m.update(force=True); m = m.to(dev)
 x = pad(synth.make_frames(1080, 1920, 1)[0].to(dev), 64)
@@ -20,7 +20,7 @@ ops.USE_GRAPHS[0] = False
 cnt, tim = collections.Counter(), collections.Counter()
 orig = ops.conv2d
 ACT = ["none", "relu", "lrelu", "gelu", "sigm", "htanh"]
-def dt(a): return "-" if a is None else str(a.dtype)[6:].replace("float32", "f32").replace("bfloat16", "bf16")
+def dt(a): return "-" if a is None else str(a.dtype)[6:].replace("float32", "f32").replace("float16", "f16")
 def wrapped(pc, inputs, out=None, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

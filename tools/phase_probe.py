@@ -10,7 +10,7 @@ from deepsvc_amd.modules import Conv2d  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_conv import SHAPES  # noqa: E402
 
-ops.set_precision("bf16")
+ops.set_precision("f16")
 ops.set_option("specialised", 0)
 dev = "cuda:0"
 L = ctypes.CDLL(N.LIB_PATH)
@@ -18,7 +18,7 @@ names = ["barrier(pre-stage)", "patch staging", "weight staging", "barrier(pre-m
 for idx in [int(a) for a in sys.argv[1:]] or [4, 2, 3, 9]:
     name, segs, cout, k, s, H, W, kw = SHAPES[idx]
     m = Conv2d(sum(segs), cout, k, s, padding=k // 2).to(dev)
-    ins = [ops.Act(torch.randn((1, H, W, c), device=dev).to(torch.bfloat16)) for c in segs]
+    ins = [ops.Act(torch.randn((1, H, W, c), device=dev).to(torch.float16)) for c in segs]
     out = m.run(ins)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 8)()

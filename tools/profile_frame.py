@@ -1,5 +1,5 @@
 """Per-shape conv time inside real P-frames: every conv launch of `steps` compress+decompress calls is bracketed by
-HIP events (ops.PROFILE hook) and aggregated by shape.  python tools/profile_frame.py [--precision bf16] [--steps 2]"""
+HIP events (ops.PROFILE hook) and aggregated by shape.  python tools/profile_frame.py [--precision f16] [--steps 2]"""
 import argparse
 import collections
 import os
@@ -15,7 +15,7 @@ from deepsvc_amd.modules import pad  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="f16")
     ap.add_argument("--steps", type=int, default=2)
     args = ap.parse_args()
     ops.set_precision(args.precision)
