@@ -347,7 +347,7 @@ def main():
     metric_rows = []
     for unit, t, bmv, bres, recon, cur in rows:
         mse = float(((harness.crop(recon, (h, w)) - harness.crop(cur, (h, w))) ** 2).mean())
-        metric_rows.append([unit, t, bmv, bres, -10 * torch.log10(torch.tensor(mse)).item() if mse > 0 else 99.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        metric_rows.append([unit, t, bmv, bres, -10 * torch.log10(torch.tensor(mse)).item() if mse > 0 else 99.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
     table = harness.gather_rows(metric_rows, dev, world)
 
     if rank == 0:

@@ -14,7 +14,10 @@ import torch.nn.functional as F
 
 from .modules import crop, pad
 
-METRIC_COLUMNS = ("unit", "frame", "bpp_mv", "bpp_res", "psnr", "psnr_mc", "psnr_warp", "t_enc", "t_dec", "msssim")
+METRIC_COLUMNS = ("unit", "frame", "bpp_mv", "bpp_res", "psnr", "psnr_mc", "psnr_warp", "t_enc", "t_dec", "msssim", "msssim_mc", "msssim_warp")
+# every key of the reference's per-run JSON (test_video.py:442-460), in its order
+REFERENCE_JSON_KEYS = ("psnr", "bpp", "msssim", "ipsnr", "ibpp", "imsssim", "ppsnr", "pbpp", "porposed_pbpp_wosm", "pmsssim", "mcpsnr", "warppsnr",
+                       "mvbpp", "resbpp", "mcmsssim", "warmsssim", "ienc", "idec", "pent", "pdec", "ent", "dec", "smbpp", "sment", "smdec", "bpp2l")
 
 
 def shard_units(n_units, rank, world_size):
@@ -64,7 +67,7 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
         sync(); t2 = time.perf_counter()
         i_psnr = _psnr(crop(ref, (h, w)), frames[0]) if metrics else 0.0
         rows.append([float(unit), 0.0, 0.0, strings_bytes(i_enc) * 8.0 / (h * w), i_psnr, 0.0, 0.0, t1 - t0, t2 - t1,
-                     _msssim(crop(ref, (h, w)), frames[0]) if msssim else 0.0])
+                     _msssim(crop(ref, (h, w)), frames[0]) if msssim else 0.0, 0.0, 0.0])
     feature = None
     for t in range(1, len(frames)):
         cur = pad(frames[t], 64)
@@ -84,7 +87,8 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
             row += [_psnr(crop(recon, (h, w)), org), _psnr(crop(predict, (h, w)), org), _psnr(crop(warped, (h, w)), org)]
         else:
             row += [0.0, 0.0, 0.0]
-        rows.append(row + [t1 - t0, t2 - t1, _msssim(crop(recon, (h, w)), frames[t]) if msssim else 0.0])
+        ms = [_msssim(crop(x, (h, w)), frames[t]) for x in (recon, predict, warped)] if msssim else [0.0, 0.0, 0.0]
+        rows.append(row + [t1 - t0, t2 - t1] + ms)
         ref = recon
     return rows
 
@@ -175,3 +179,57 @@ def summarise(table):
             "warppsnr": float(cols["psnr_warp"].mean()) if n else 0.0,
             "pent": float(cols["t_enc"].mean()) if n else 0.0, "pdec": float(cols["t_dec"].mean()) if n else 0.0,
             "pmsssim": float(cols["msssim"].mean()) if n else 0.0}
+
+
+def reference_results(table, sm_rows=None):
+    """The `results` dict of the reference's per-run JSON (test_video.py:353-460): all 26 keys, each a list
+    with one entry per SEQUENCE (= `unit` of the metric rows), computed exactly as the reference averages them:
+      * I-frame rows (frame index 0 with bpp_mv == 0 and a key-frame bpp in `bpp_res`) feed ipsnr / ibpp / imsssim / ienc / idec;
+      * P-frame rows feed ppsnr / pbpp / pmsssim / mcpsnr / warppsnr / mvbpp / resbpp / mcmsssim / warmsssim / pent / pdec;
+      * psnr / bpp / msssim / ent / dec / porposed_pbpp_wosm / bpp2l average over ALL frames of the sequence (:370-391);
+      * the semantic layer's rate and time (`smbpp`, `sment`, `smdec`; test_video.py:336-337,386-391) come from `sm_rows`
+        = {unit: [(sm_bpp, enct, dect) per P-frame]} when a semantic-layer codec produced `sm_fea`, else they are 0 --
+        p_bpp = mv + res + sm (:366), bpp2l = mv + sm for P-frames and the I-frame bpp for I-frames (:318,384), and the
+        reference ADDS the semantic layer's times to pent / pdec / ent / dec (:388-391)."""
+    import numpy as np
+    cols = {n: i for i, n in enumerate(METRIC_COLUMNS)}
+    t = table.numpy() if hasattr(table, "numpy") else np.asarray(table)
+    out = {k: [] for k in REFERENCE_JSON_KEYS}
+    avg = lambda v: float(np.average(v)) if len(v) else float("nan")
+    for unit in sorted(set(t[:, cols["unit"]].tolist())):
+        rows = t[t[:, cols["unit"]] == unit]
+        rows = rows[np.argsort(rows[:, cols["frame"]], kind="stable")]
+        is_i = (rows[:, cols["frame"]] == 0)
+        I, P = rows[is_i], rows[~is_i]
+        sm = np.asarray(sm_rows[unit], dtype=np.float64).reshape(-1, 3) if sm_rows and unit in sm_rows else np.zeros((len(P), 3))
+        assert len(sm) == len(P), "one (sm_bpp, enct, dect) triple per P-frame"
+        g = lambda R, n: R[:, cols[n]]
+        i_bpp = g(I, "bpp_res")
+        p_wosm = g(P, "bpp_mv") + g(P, "bpp_res")
+        p_bpp = p_wosm + sm[:, 0]
+        p_enc, p_dec = g(P, "t_enc") + sm[:, 1], g(P, "t_dec") + sm[:, 2]
+        out["psnr"].append(avg(np.concatenate([g(I, "psnr"), g(P, "psnr")])))
+        out["bpp"].append(avg(np.concatenate([i_bpp, p_bpp])))
+        out["msssim"].append(avg(np.concatenate([g(I, "msssim"), g(P, "msssim")])))
+        out["ipsnr"].append(avg(g(I, "psnr"))); out["ibpp"].append(avg(i_bpp)); out["imsssim"].append(avg(g(I, "msssim")))
+        out["ppsnr"].append(avg(g(P, "psnr"))); out["pbpp"].append(avg(p_bpp))
+        out["porposed_pbpp_wosm"].append(avg(np.concatenate([i_bpp, p_wosm])))
+        out["pmsssim"].append(avg(g(P, "msssim")))
+        out["mcpsnr"].append(avg(g(P, "psnr_mc"))); out["warppsnr"].append(avg(g(P, "psnr_warp")))
+        out["mvbpp"].append(avg(g(P, "bpp_mv"))); out["resbpp"].append(avg(g(P, "bpp_res")))
+        out["mcmsssim"].append(avg(g(P, "msssim_mc"))); out["warmsssim"].append(avg(g(P, "msssim_warp")))
+        out["ienc"].append(avg(g(I, "t_enc"))); out["idec"].append(avg(g(I, "t_dec")))
+        out["pent"].append(avg(p_enc)); out["pdec"].append(avg(p_dec))
+        out["ent"].append(avg(np.concatenate([g(I, "t_enc"), p_enc]))); out["dec"].append(avg(np.concatenate([g(I, "t_dec"), p_dec])))
+        out["smbpp"].append(avg(sm[:, 0])); out["sment"].append(avg(sm[:, 1])); out["smdec"].append(avg(sm[:, 2]))
+        out["bpp2l"].append(avg(np.concatenate([i_bpp, g(P, "bpp_mv") + sm[:, 0]])))
+    return out
+
+
+def write_reference_json(path, table, name, sm_rows=None):
+    """test_video.py:452-460: {"name", "description": "Inference (ans)", "results": {...}} with indent 2."""
+    import json
+    output = {"name": name, "description": "Inference (ans)", "results": reference_results(table, sm_rows)}
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(output, f, indent=2)
+    return output

@@ -125,6 +125,12 @@ def test_gop_with_intra_coded_key_frame():
         assert all(np.isfinite(r[4]) for r in rows)
         table = harness.gather_rows(rows, torch.device(DEV), 1)
         assert table.shape == (4, len(harness.METRIC_COLUMNS))
+        # the reference's per-run JSON (test_video.py:442-460) from a real coded GOP: all 26 keys, finite where defined
+        res = harness.reference_results(table)
+        assert tuple(res) == harness.REFERENCE_JSON_KEYS
+        for k, v in res.items():
+            assert len(v) == 1 and np.isfinite(v[0]), (k, v)
+        assert 0 < res["warmsssim"][0] <= 1 and 0 < res["mcmsssim"][0] <= 1 and res["ibpp"][0] > 0 and res["smbpp"][0] == 0.0
     finally:
         ops.set_precision("fp32")
 
@@ -149,6 +155,46 @@ def test_config3_gop12_four_rate_points():
             p_bpp = float(np.mean([r[2] + r[3] for r in rows[1:]]))
             points.append((lam, i_bpp, i_psnr, p_bpp, float(np.mean([r[4] for r in rows[1:]]))))
             print(f"lambda {lam}: I {i_bpp:.3f} bpp {i_psnr:.2f} dB | P mean {p_bpp:.3f} bpp {points[-1][4]:.2f} dB")
+        for lo, hi in zip(points[:-1], points[1:]):
+            assert hi[1] > lo[1] and hi[3] > lo[3], f"rate not increasing with lambda: {lo} -> {hi}"
+            assert hi[2] > lo[2] - 0.05, f"key-frame PSNR not increasing with lambda: {lo} -> {hi}"
+    finally:
+        ops.set_precision("fp32")
+
+
+def test_config3_1080p_gop12_four_rate_points():
+    """BASELINE.json config 3 at its full size: 1920x1080 (padded 1088x1920), GOP = 12, key frame coded by `ICIP2020ResB`, four
+    operating points (synth.RATE_GAINS stand-ins for lambda in {256, 512, 1024, 2048}), f16 mode.  The CPU oracle is too slow
+    at this size, so size-independent properties: every frame decodes to a finite picture in [0,1]; coding the GOP twice gives
+    bit-identical rows (deterministic kernels, encoder/decoder lock-step through a real bitstream), including the decoded latents
+    of the last P-frame; rate is monotone in lambda for the I-frame and for the P-frames."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("f16")
+    try:
+        H, W, gop = 1080, 1920, 12
+        frames = [f.to(DEV) for f in synth.make_frames(H, W, gop, seed=21)]
+        sms = [None] + [synth.make_sm_fea(1088, 1920, t, seed=21).to(DEV) for t in range(1, gop)]
+        points = []
+        for lam in (256, 512, 1024, 2048):
+            i_model = synth.make_icodec("W0", lam=lam); i_model.update(force=True); i_model = i_model.to(DEV)
+            p_model = synth.make_model("W0", lam=lam); p_model.update(force=True); p_model = p_model.to(DEV)
+            rows = harness.code_gop(p_model, frames, sms, unit=0, sync=torch.cuda.synchronize, i_model=i_model)
+            dev = torch.device(DEV)
+            dec_lat = [c._plan(1, 68, 120, dev).y_hat.buf.clone() for c in (p_model.mv_codec, p_model.res_codec)]
+            assert len(rows) == gop and all(np.isfinite(v) for r in rows for v in r)
+            if lam == 2048:
+                again = harness.code_gop(p_model, frames, sms, unit=0, sync=torch.cuda.synchronize, i_model=i_model)
+                assert [r[:7] for r in again] == [r[:7] for r in rows], "coding the same GOP twice gave different rows"
+                lat2 = [c._plan(1, 68, 120, dev).y_hat.buf for c in (p_model.mv_codec, p_model.res_codec)]
+                assert all(torch.equal(a, b) for a, b in zip(dec_lat, lat2))
+            i_bpp, i_psnr = rows[0][3], rows[0][4]
+            p_bpp = float(np.mean([r[2] + r[3] for r in rows[1:]]))
+            t_frame = float(np.mean([r[7] + r[8] for r in rows[1:]]))
+            points.append((lam, i_bpp, i_psnr, p_bpp, float(np.mean([r[4] for r in rows[1:]]))))
+            print(f"config 3 @1080p lambda {lam}: I {i_bpp:.3f} bpp {i_psnr:.2f} dB ({1e3 * (rows[0][7] + rows[0][8]):.1f} ms) | "
+                  f"P mean {p_bpp:.3f} bpp {points[-1][4]:.2f} dB ({1e3 * t_frame:.1f} ms/frame, one lane, joined coder timing)")
+            del i_model, p_model
+            torch.cuda.empty_cache()
         for lo, hi in zip(points[:-1], points[1:]):
             assert hi[1] > lo[1] and hi[3] > lo[3], f"rate not increasing with lambda: {lo} -> {hi}"
             assert hi[2] > lo[2] - 0.05, f"key-frame PSNR not increasing with lambda: {lo} -> {hi}"

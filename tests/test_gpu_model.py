@@ -135,6 +135,49 @@ def test_forward1_matches_oracle(model, oracle_w0):
         assert abs(float(a) - float(b)) <= (0.01 if n == "bpp_mv" else 1e-3) * abs(float(b)), f"{n}: {float(a)} vs {float(b)}"
 
 
+def test_f16_stage_blocks_vs_oracle_with_f16_weights(oracle_w0):
+    """f16 mode stage by stage (the kernels of the fast path -- ping-pong / weight-stationary / 1x1 streaming / fused tails -- run
+    here, not the fp32 ones): every block of the decoder tail against the fp32 oracle evaluated with f16-ROUNDED WEIGHTS on
+    f16-rounded inputs.  What is left is the rounding of the stored activations: relative L2 a few 1e-4 per stored tensor;
+    bound 3e-3 (a skipped block or a wrong tap is >= 1e-2)."""
+    import parity_util as PU
+    from deepsvc_amd import ops, synth
+    from oracle import nets
+    from oracle.codec import DeepSVCOracle
+    h = lambda t: t.to(torch.float16).float()
+    sd16 = {k: (h(v) if v.is_floating_point() and v.dim() == 4 else v) for k, v in oracle_w0.sd.items()}     # conv weights only
+    root = DeepSVCOracle(sd16).root
+    ops.set_precision("f16")
+    try:
+        m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+        torch.manual_seed(3)
+        size = 128
+        fr, sm = synth.make_frames(size, size, 2), synth.make_sm_fea(size, size, 1)
+        got, want = {}, {}
+        x64 = h(torch.randn(1, 64, size, size) * 0.3)
+        x96 = h(torch.randn(1, 96, size, size) * 0.3)
+        mv = torch.randn(1, 2, size, size) * 2
+        warped = nets.warp(fr[0], mv)
+        got["FeatureExtractor"], want["FeatureExtractor"] = m.FeatureExtractor(fr[1].to(DEV)), nets.feature_extraction(root.sub("FeatureExtractor"), fr[1])
+        got["unet_1"], want["unet_1"] = m.enhance.unet_1(x64.to(DEV)), nets.unet(root.sub("enhance.unet_1"), x64)
+        f, r = m.enhance(x96.to(DEV))
+        fw, rw = nets.reconstruction(root.sub("enhance"), x96)
+        got["enhance feature"], want["enhance feature"], got["enhance recon"], want["enhance recon"] = f, fw, r, rw
+        got["RefineResiNet"], want["RefineResiNet"] = m.RefineResiNet(x64.to(DEV), fr[0].to(DEV)), nets.refine_net(root.sub("RefineResiNet"), x64, fr[0])
+        got["RefineMvNet"], want["RefineMvNet"] = m.RefineMvNet(mv.to(DEV), fr[0].to(DEV)), nets.refine_net(root.sub("RefineMvNet"), mv, fr[0])
+        for tag, feature in (("first", None), ("steady", x64)):
+            up, pred = m.MC(fr[0].to(DEV), warped.to(DEV), mv.to(DEV), sm.to(DEV), None if feature is None else feature.to(DEV))
+            upw, predw = nets.inter_layer_prediction(root.sub("MC"), fr[0], warped, mv, sm, feature)
+            got[f"MC up_out {tag}"], want[f"MC up_out {tag}"], got[f"MC predict {tag}"], want[f"MC predict {tag}"] = up, upw, pred, predw
+        got["opticFlow"], want["opticFlow"] = m.opticFlow(fr[1].to(DEV), fr[0].to(DEV)), nets.spynet(root.sub("opticFlow"), fr[1], fr[0])
+    finally:
+        ops.set_precision("fp32")
+    for k in got:
+        e = PU.rel_l2(got[k].float().cpu(), want[k])
+        print(f"[f16 stage] {k}: rel-L2 {e:.2e}")
+        assert e <= 3e-3, f"{k}: rel-L2 {e:.3e}"
+
+
 def test_full_size_1080p_roundtrip_properties(oracle_w0):
     """BASELINE.json configs[1] size (1920x1080 -> padded 1088x1920), where the CPU oracle is too slow to be the
     checker: size-independent properties of the real bitstream path instead.

@@ -1,12 +1,13 @@
 """GPU parity of every HIP op, called through the C ABI (deepsvc_amd.ops), against plain PyTorch-CPU fp32
 (or the oracle's restatement) on the same seeded inputs.  Tolerances: fp32 MFMA path 1e-4 relative to the
-output scale; f16 MFMA path is compared with a reference fed the same f16-rounded operands (5e-3)."""
+output scale; the f16 MFMA path is compared with an fp32 reference fed the same f16-rounded operands at HALF AN ULP of the
+stored value plus 3e-5 of the tensor scale for the summation order (gpu_util.close_f16) -- tight enough that one wrong tap fails."""
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import report_close
+from gpu_util import close_f16, report_close
 
 pytestmark = pytest.mark.gpu
 
@@ -65,8 +66,10 @@ def test_conv_plain(case, compute):
     if compute == "f16":
         x, w = x.to(torch.float16).float(), w.to(torch.float16).float()
     want = F.conv2d(x, w, m.bias.detach().cpu(), stride=s, padding=k // 2)
-    tol = 2e-4 if compute == "fp32" else 5e-3
-    report_close(f"conv {case} {compute}", got, want, tol, tol * float(want.abs().max()))
+    if compute == "f16":
+        close_f16(f"conv {case} f16", got, want, out_f16=False)
+    else:
+        report_close(f"conv {case} fp32", got, want, 2e-4, 2e-4 * float(want.abs().max()))
 
 
 @pytest.mark.parametrize("act", [0, 1, 2, 3, 4, 5])
@@ -114,7 +117,7 @@ def test_conv_slices_shuffle_and_f16_storage():
     got = mm.run(_act(x, torch.float16), res1=_act(res, torch.float16), out_dtype=torch.float16)
     assert got.dtype == torch.float16
     want = F.conv2d(x.to(torch.float16).float(), mm.weight.cpu(), mm.bias.cpu(), padding=1) + res.to(torch.float16).float()
-    report_close("f16 storage", got.nchw().cpu(), want, 1e-2, 1e-2)
+    report_close("f16 storage in fp32 compute mode (one f16 rounding of the output)", got.nchw().cpu(), want, 6e-4, 2e-4)
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 250, 1100), (64, 32, 256, 1024), (64, 3, 264, 1000), (32, 64, 250, 1090), (32, 3, 256, 1056), (3, 64, 250, 1100)])
@@ -137,10 +140,10 @@ def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
     xb = x.to(bf).float()
     want = F.conv2d(xb, w, b, padding=1)
-    report_close("rs plain", plain, want, 5e-3, 5e-3 * float(want.abs().max()))
+    close_f16("rs plain", plain, want, out_f16=False)
     pre = F.leaky_relu(xb, 0.01).to(bf).float()
     want2 = F.leaky_relu(F.conv2d(pre, w, b, padding=1), 0.01) + r1.to(bf).float() + r2.to(bf).float()
-    report_close("rs fused", fused, want2, 2e-2, 2e-2 * float(want2.abs().max()))
+    close_f16("rs fused", fused, want2)
 
 
 @pytest.mark.parametrize("segs,cout,B,H,W,pre,act,nres", [
@@ -187,9 +190,9 @@ def test_conv3x3_pingpong_kernel(segs, cout, B, H, W, pre, act, nres):
     for r in rs:
         want = want + r.to(bf).float()
     assert got.shape == want.shape
-    tol = 2e-2 * float(want.abs().max())
-    report_close("pp vs torch", got, want, 2e-2, tol)
-    report_close("pp vs ws", got, other, 1e-2, 1e-2 * float(want.abs().max()))
+    close_f16("pp (f16 out) vs torch", got, want)
+    close_f16("ws / generic (fp32 out) vs torch", other, want, out_f16=False)
+    close_f16("pp f16-out vs the fp32-out launch of the same conv: one correct rounding", got, other)
 
 
 @pytest.mark.parametrize("cin,cout,H,W,act,res,out_dt", [
@@ -227,8 +230,8 @@ def test_conv3x3_pingpong_narrow_head(cin, cout, H, W, act, res, out_dt):
     if res:
         want = want + (r.to(bf).float() if res == "f16" else r)
     rt = 2e-2 if out_dt == "f16" else 5e-3
-    report_close("head vs torch", got, want, rt, rt * float(want.abs().max()))
-    report_close("head vs ws", got, other, rt, rt * float(want.abs().max()))
+    close_f16("head vs torch", got, want, out_f16=(out_dt == "f16"))
+    close_f16("head vs ws", got, other, out_f16=(out_dt == "f16"))
 
 
 @pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,act,res,out_dt", [
@@ -268,7 +271,7 @@ def test_conv3x3_small_image_scan_net_shapes(segs, seg_dt, cout, B, H, W, act, r
     if res:
         want = want + (r.to(bf).float() if res == "f16" else r)
     tol = (2e-2 if out_dt == "f16" else 5e-3) * float(want.abs().max())
-    report_close("small conv vs torch", got, want, 2e-2 if out_dt == "f16" else 5e-3, tol)
+    close_f16("small conv vs torch", got, want, out_f16=(out_dt == "f16"))
 
 
 @pytest.mark.parametrize("segs,cout,k,stride,B,H,W,pre,act,res", [
@@ -319,7 +322,7 @@ def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, 
     want = _torch_act(F.conv2d(xb, w, b, stride=stride, padding=k // 2), act, 0.05)
     if res:
         want = want + r.to(bf).float()
-    report_close("register epilogue vs torch", reg, want, 1.5e-2, 1.5e-2 * float(want.abs().max()))
+    close_f16("register epilogue vs torch", reg, want)
 
 
 @pytest.mark.parametrize("segs,cout,k,stride,H,W,act,res", [
@@ -352,7 +355,7 @@ def test_conv_wide_output_variants(segs, cout, k, stride, H, W, act, res):
     want = _torch_act(F.conv2d(xs[0].to(bf).float(), w, b, stride=stride, padding=k // 2), act, 0.05)
     if res:
         want = want + r.to(bf).float()
-    report_close("wide conv vs torch", got, want, 5e-3, 5e-3 * float(want.abs().max()))
+    close_f16("wide conv vs torch", got, want, out_f16=False)
 
 
 @pytest.mark.parametrize("segs,cout,k,B,H,W,pre,act,res", [
@@ -392,7 +395,7 @@ def test_conv_tall_tile_variant(segs, cout, k, B, H, W, pre, act, res):
     want = _torch_act(F.conv2d(xb, w, b, padding=k // 2), act, 0.05)
     if res:
         want = want + r.to(bf).float()
-    report_close("tall tile vs torch", tall, want, 5e-3, 5e-3 * float(want.abs().max()))
+    close_f16("tall tile vs torch", tall, want, out_f16=False)
 
 
 @pytest.mark.parametrize("segs,seg_dt,cout,B,H,W,pre,act", [
@@ -421,7 +424,7 @@ def test_conv_fp32_storage_converted_while_staged(segs, seg_dt, cout, B, H, W, p
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
     xb = torch.cat([_torch_act(x.to(bf).float() if t == "f16" else x, pre, 0.05).to(bf).float() for x, t in zip(xs, seg_dt)], 1)
     want = _torch_act(F.conv2d(xb, w, b, padding=1), act, 0.05)
-    report_close("converted staging vs torch", got, want, 5e-3, 5e-3 * float(want.abs().max()))
+    close_f16("converted staging vs torch", got, want, out_f16=False)
 
 
 @pytest.mark.parametrize("segs,cout,B,H,W", [((8, 64, 8), 96, 1, 64, 96), ((8,), 64, 2, 128, 160), ((8, 64, 8), 96, 1, 272, 480),
@@ -451,9 +454,8 @@ def test_conv5x5s2_space_to_depth_view(segs, cout, B, H, W):
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
     want = F.conv2d(torch.cat([x.to(bf).float() for x in xs], 1), w, b, stride=2, padding=2)
     assert got.shape == want.shape == (B, cout, H // 2, W // 2)
-    tol = 5e-3 * float(want.abs().max())
-    report_close("s2d vs torch", got, want, 5e-3, tol)
-    report_close("s2d vs direct 5x5/s2", got, direct, 5e-3, tol)
+    close_f16("s2d vs torch", got, want, out_f16=False)
+    close_f16("s2d vs direct 5x5/s2", got, direct, out_f16=False)
 
 
 @pytest.mark.parametrize("B,H,W,slope", [(1, 256, 1024, 0.01), (1, 250, 1100, 0.01), (2, 130, 1000, 0.0)])
@@ -484,9 +486,10 @@ def test_res_bottleneck_fused_tail(B, H, W, slope):
     o1 = r(act(F.conv2d(xb, r(m.conv1.weight.detach().cpu()), m.conv1.bias.detach().cpu())))
     o2 = r(act(F.conv2d(o1, r(m.conv2.weight.detach().cpu()), m.conv2.bias.detach().cpu(), padding=1)))
     want = F.conv2d(o2, r(m.conv3.weight.detach().cpu()), m.conv3.bias.detach().cpu()) + xb
-    tol = 2e-2 * float(want.abs().max())
-    report_close("fused vs torch", fused, want, 2e-2, tol)
-    report_close("fused vs three launches", fused, plain, 1e-2, 0.5 * tol)
+    # the f16-rounded intermediates (o1, o2) can round the other way than the emulation's on isolated elements: one ulp of an
+    # intermediate times a 1x1 weight, far below a missing tap (extra = 3e-4 of the tensor scale)
+    close_f16("fused vs torch", fused, want, extra=3e-4)
+    close_f16("fused vs three launches", fused, plain, extra=3e-4)
 
 
 @pytest.mark.parametrize("segs,cout", [((32, 32), 64), ((64, 64), 64), ((64,), 32), ((64, 32), 128)])
@@ -509,7 +512,7 @@ def test_conv1x1_gated_two_segment(segs, cout):
         ops.set_precision("fp32")
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
     want = F.conv2d(torch.cat([x.to(bf).float() for x in xs], 1), w, b) + gate[:, :, None, None] * r1.to(bf).float()
-    report_close("gated 1x1", got, want, 2e-2, 2e-2 * float(want.abs().max()))
+    close_f16("gated 1x1", got, want)
 
 
 @pytest.mark.parametrize("cin,cout,act,res", [(64, 64, 2, True), (96, 96, 0, True), (96, 96, 2, False), (128, 128, 1, True),
@@ -537,9 +540,9 @@ def test_conv1x1_register_epilogue(cin, cout, act, res):
     want = _torch_act(F.conv2d(x.to(bf).float(), w, b), act, 0.05)
     if res:
         want = want + r1.to(bf).float()
-    tol = 2e-2 * float(want.abs().max())
-    report_close("1x1 register epilogue vs torch", got, want, 2e-2, tol)
-    report_close("1x1 register vs slab epilogue", got, slab, 1e-2, 0.5 * tol)
+    close_f16("1x1 register epilogue vs torch", got, want)
+    close_f16("1x1 slab epilogue (fp32 out) vs torch", slab, want, out_f16=False)
+    close_f16("1x1 f16-out vs the fp32-out launch of the same conv: one correct rounding", got, slab)
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (96, 96), (32, 64), (64, 128), (128, 64), (64, 32)])
@@ -562,9 +565,9 @@ def test_conv1x1_streaming_kernel(cin, cout):
         ops.set_precision("fp32")
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
     y = F.conv2d(x.to(bf).float(), w, b)
-    report_close("1x1 lrelu", plain, F.leaky_relu(y, 0.01), 5e-3, 5e-3 * float(y.abs().max()))
+    close_f16("1x1 lrelu", plain, F.leaky_relu(y, 0.01), out_f16=False)
     want = y + gate[:, :, None, None] * r1.to(bf).float() + r2
-    report_close("1x1 fused", fused, want, 2e-2, 2e-2 * float(want.abs().max()))
+    close_f16("1x1 fused", fused, want)
 
 
 def test_warp_matches_grid_sample():
