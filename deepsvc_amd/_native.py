@@ -70,6 +70,8 @@ SIGNATURES = {
     "dsvc_se_workspace_floats": (c_int64, [c_int32, c_int32]),
     "dsvc_se_gate": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                              c_void_p, c_void_p]),
+    "dsvc_refine_aggregate": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
+                                      c_void_p, c_int32]),
     "dsvc_reduce_workspace_floats": (c_int64, []),
     "dsvc_reduce": (c_int, [c_void_p, c_int32, c_int64, c_int32, POINTER(Operand), POINTER(Operand), c_void_p, c_void_p]),
     "dsvc_ssim_workspace_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32]),

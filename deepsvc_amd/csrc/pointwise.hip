@@ -451,6 +451,57 @@ __global__ void reduce_final_kernel(const float* partial, int n, double* out) {
 inline Opnd mk(const dsvc_operand* o) { return o ? Opnd{o->ptr, o->ld, o->dtype} : Opnd{nullptr, 0, 0}; }
 inline bool dt_ok(int dt) { return dt == DSVC_F32 || dt == DSVC_F16; }
 
+// ---- RefineNet1 temporal aggregation (semantic_layer.py:1166-1184) -----------------------------------------------------------
+// Per pixel: n(v) = v / ||v||_2 over the C channels; a_l = mean_c (or sum_c) n(rx)[c] * n(rs_l)[c]; w = softmax_l(a);
+// out[c] = x[c] + sum_l x[c] * w_l  (evaluated in that order: the weights sum to 1 only up to rounding), optional ReLU
+// (OursResNetStudentP.act, semantic_layer.py:1082).  One wave per pixel, C/64 channels per lane (C = 256: one float4 per lane),
+// wave-wide sums through DPP-free shuffles in a fixed order (deterministic).  HBM-bound: reads (2 + L) * C floats per pixel.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int MAXL>
+__global__ void __launch_bounds__(256) refine_aggregate_kernel(const float* x, int x_ld, const float* rx, int rx_ld, const float* rs, int rs_ld,
+                                                               int64_t rs_img, int L, int64_t npix, int C, int mean, int relu,
+                                                               float* out, int out_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= npix) return;
+    const int per = C / 64;                       // channels per lane (host checks C % 64 == 0, per <= 4)
+    float xv[4], rv[4];
+    float n2 = 0.f;
+    for (int j = 0; j < per; ++j) {
+        xv[j] = x[pix * x_ld + lane * per + j];
+        rv[j] = rx[pix * rx_ld + lane * per + j];
+        n2 += rv[j] * rv[j];
+    }
+    const float nx = sqrtf(wave_sum(n2));
+    float a[MAXL];
+    float amax = -__builtin_inff();
+    for (int l = 0; l < L; ++l) {
+        float sv[4], s2 = 0.f, dot = 0.f;
+        for (int j = 0; j < per; ++j) {
+            sv[j] = rs[l * rs_img + pix * rs_ld + lane * per + j];
+            s2 += sv[j] * sv[j];
+        }
+        const float ns = sqrtf(wave_sum(s2));
+        for (int j = 0; j < per; ++j) dot += (rv[j] / nx) * (sv[j] / ns);
+        a[l] = wave_sum(dot) * (mean ? 1.f / (float)C : 1.f);
+        amax = fmaxf(amax, a[l]);
+    }
+    float den = 0.f;
+    for (int l = 0; l < L; ++l) { a[l] = expf(a[l] - amax); den += a[l]; }
+    for (int j = 0; j < per; ++j) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc += xv[j] * (a[l] / den);
+        float o = xv[j] + acc;
+        if (relu) o = fmaxf(o, 0.f);
+        out[pix * out_ld + lane * per + j] = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int dsvc_warp_bilinear_border(void* stream, const void* in, int32_t in_ld, int32_t in_dtype,
@@ -556,6 +607,17 @@ extern "C" int dsvc_eltwise(void* stream, int32_t op, int64_t n_pix, int32_t C, 
         hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n_pix * C)), dim3(kThreads), 0, (hipStream_t)stream, op, n_pix, C,
                            mk(a), mk(b), mk(c), mk(d), mk(e), out, out_ld, out_dtype);
     DSVC_CHECK_LAUNCH("eltwise_kernel");
+    return DSVC_OK;
+}
+
+extern "C" int dsvc_refine_aggregate(void* stream, const float* x, int32_t x_ld, const float* rx, int32_t rx_ld, const float* rs, int32_t rs_ld,
+                                     int32_t L, int64_t n_pix, int32_t C, int32_t mean, int32_t relu, float* out, int32_t out_ld) {
+    DSVC_REQUIRE(x && rx && rs && out && n_pix > 0 && L >= 1 && L <= 16, "refine_aggregate: bad argument (1 <= supports <= 16)");
+    DSVC_REQUIRE(C > 0 && C % 64 == 0 && C <= 256 && x_ld >= C && rx_ld >= C && rs_ld >= C && out_ld >= C, "refine_aggregate: C=%d must be 64..256, multiple of 64", C);
+    const int64_t blocks = (n_pix + 3) / 4;
+    hipLaunchKernelGGL(refine_aggregate_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, rx, rx_ld, rs, rs_ld,
+                       n_pix * rs_ld, L, n_pix, C, mean, relu, out, out_ld);
+    DSVC_CHECK_LAUNCH("refine_aggregate_kernel");
     return DSVC_OK;
 }
 

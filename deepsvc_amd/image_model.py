@@ -107,8 +107,11 @@ class _ScanPlan:
         # (means, scales) and every slice's (mu_i, sigma_i) sit in ONE buffer each, pair after pair: the mean and the scale
         # stack of a scan level run as batch items of single launches (ops.conv2d items=...), which read / write them at a
         # fixed item stride
-        self.pair = ops.new_act(2 * B, h, w, Mc, F32, device)
-        self.means, self.scales = ops.Act(self.pair.buf[:B]), ops.Act(self.pair.buf[B:])
+        # (a codec whose parameter nets are also conditioned on a side feature -- semantic_layer.cFeatureCompress -- keeps that
+        # feature in `latent_extra` further channels of the same pixel rows, so cat[latent, side, supports] stays <= 3 segments)
+        extra = getattr(codec, "latent_extra", 0)
+        self.pair = ops.new_act(2 * B, h, w, Mc + extra, F32, device)
+        self.means, self.scales = ops.Act(self.pair.buf[:B], 0, Mc), ops.Act(self.pair.buf[B:], 0, Mc)
         self.z_hat = act(h // 4, w // 4, Nc)
         self.musc = ops.new_act(2 * B * codec.num_slices, h, w, d, F32, device)
         self.mus = [ops.Act(self.musc.buf[2 * i * B:(2 * i + 1) * B]) for i in range(codec.num_slices)]
@@ -256,8 +259,16 @@ class ChannelSplitICIP2020ResB(nn.Module):
     def _stack(self, stack, segments, out=None, **last_epilogue):
         return _run_stack(stack, segments, out, self._stack_act[0], self._stack_act[1], **last_epilogue)
 
+    latent_extra = 0         # side-feature channels stored behind the latent means / scales (see _ScanPlan)
+
+    def _latent_seg(self, latent):
+        """The first segment of every parameter-net input: the hyper-prior's means (or scales), plus the side feature kept
+        behind them when the codec has one."""
+        return latent if self.latent_extra == 0 else Act(latent.buf, latent.c0, latent.C + self.latent_extra)
+
     def _support(self, latent, y_hat, i):
         k = min(i, self.max_support_slices)
+        latent = self._latent_seg(latent)
         return [latent] if k == 0 else [latent, y_hat.ch(0, k * self.slice_depth)]
 
     def _slice_params(self, i, means, scales, y_hat, mu_out=None, sc_out=None):
@@ -311,6 +322,7 @@ class ChannelSplitICIP2020ResB(nn.Module):
         """y_hat_i += 0.5*tanh(lrp_i(cat[mean_support, y_hat_i])) in place (image_model.py:185-188,244-247,292-295)."""
         d = self.slice_depth
         cur = y_hat.ch(i * d, d)
+        means = self._latent_seg(means)
         if i < self.max_support_slices:
             segs = [means, y_hat.ch(0, (i + 1) * d)]
         else:

@@ -431,6 +431,17 @@ def se_gate(x, w1, w2):
     return gate
 
 
+def refine_aggregate(x, rx, rs, mean=True, relu=False):
+    """RefineNet1's aggregation (include/dsvc.h: dsvc_refine_aggregate): x, rx [1,H,W,C] fp32 Acts, rs [L,H,W,C] fp32 Act."""
+    for a in (x, rx, rs):
+        _require_gpu(a.buf)
+        assert a.dtype == torch.float32, "refine_aggregate works on fp32 features"
+    out = new_act(1, x.H, x.W, x.C, torch.float32, x.device)
+    N.check(N.lib().dsvc_refine_aggregate(_stream(), x.ptr, x.ld, rx.ptr, rx.ld, rs.ptr, rs.ld, rs.B, x.npix, x.C, int(bool(mean)), int(bool(relu)),
+                                          out.ptr, out.ld), "refine_aggregate")
+    return out
+
+
 def reduce(mode, a, b=None):
     """mode: 'sum' | 'sumlog' | 'sqdiff' -> 0-dim fp64 device tensor."""
     L = N.lib()

@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CALIBRATION = os.path.join(HERE, "data", "w0_calibration.json")
 CALIBRATIONS = {"W0": CALIBRATION, "W1": os.path.join(HERE, "data", "w1_calibration.json")}
 ICIP_CALIBRATION = os.path.join(HERE, "data", "icip_w0_calibration.json")
+FCODEC_CALIBRATION = os.path.join(HERE, "data", "fcodec_w0_calibration.json")
 
 
 def make_frames(H, W, n_frames, seed=1234):
@@ -111,6 +112,36 @@ def make_icodec(weight_set="W0", calibrated=True, lam=2048):
     torch.random.set_rng_state(rng)
     if calibrated:
         sd = apply_rate_point(apply_calibration(model.state_dict(), load_calibration(ICIP_CALIBRATION)), lam, codecs=("",))
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(sd[k])
+    model.eval()
+    return model
+
+
+def make_semantic_input(H, W, t, seed=1234):
+    """Stand-ins for the semantic layer's inputs at frame t: the normalised image `process(frame * 255)`
+    (test_video.py:176-190,336: per-channel (v - mean) / std, channel order reversed) is replaced by N(0,1) noise smoothed like the
+    frames; `supp` [2,256,H/4,W/4] = two post-ReLU support features (test_video.py:333-334,338: cat of the teacher's / previous
+    frames' layer-1 outputs)."""
+    g = torch.Generator().manual_seed(seed + 77 * t)
+    x = F.interpolate(torch.randn((1, 3, H // 8 + 1, W // 8 + 1), generator=g), size=(H, W), mode="bilinear", align_corners=False)
+    x = x + 0.05 * torch.randn((1, 3, H, W), generator=g)
+    supp = torch.relu(torch.randn((2, 256, H // 4, W // 4), generator=g))
+    return x.contiguous(), supp
+
+
+def make_student_layer1(weight_set="W0", calibrated=True):
+    """Product `StudentLayer1` (semantic-layer feature codec + RefineNet1) on the CPU with the named
+    synthetic weight set: seeded default init x deepsvc_amd/data/fcodec_w0_calibration.json (tools/calibrate_fcodec.py)."""
+    from .semantic_layer import StudentLayer1
+    seed = {"W0": 0, "W1": 1}[weight_set]
+    rng = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = StudentLayer1(N=72)
+    torch.random.set_rng_state(rng)
+    if calibrated:
+        sd = apply_calibration(model.state_dict(), load_calibration(FCODEC_CALIBRATION))
         with torch.no_grad():
             for k, v in model.state_dict().items():
                 v.copy_(sd[k])

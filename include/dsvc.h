@@ -174,6 +174,13 @@ int dsvc_se_gate(void* stream, const void* x, int32_t ld, int32_t dtype, int32_t
                  const float* w1 /*[C/r][C]*/, const float* w2 /*[C][C/r]*/, int32_t hidden,
                  float* partial, float* gate /*[B][C]*/);
 
+/* RefineNet1's temporal aggregation (semantic_layer.py:1166-1184), fp32 NHWC, one image x against L
+ * support images: per pixel n(v) = v/||v||_2 over C channels, a_l = mean_c (mean != 0) or sum_c of n(rx)*n(rs_l),
+ * w = softmax_l(a), out = x + sum_l x*w_l, then ReLU when relu != 0 (semantic_layer.py:1082).  rs: [L][n_pix][rs_ld].
+ * C in {64, 128, 192, 256}, L <= 16.  Deterministic. */
+int dsvc_refine_aggregate(void* stream, const float* x, int32_t x_ld, const float* rx, int32_t rx_ld, const float* rs, int32_t rs_ld,
+                          int32_t L, int64_t n_pix, int32_t C, int32_t mean, int32_t relu, float* out, int32_t out_ld);
+
 /* deterministic reductions into out[0] (fp64 accumulate in the final stage); partial: workspace of
  * dsvc_reduce_workspace_floats() floats.
  * mode 0: sum(a)   1: sum(log(a))   2: sum((a-b)^2)   (video_model.py:38-42,46,53-56,68) */
