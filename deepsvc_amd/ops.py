@@ -370,7 +370,7 @@ def items_ok(acts):
     for a in acts:
         es = a.buf.element_size()
         same = a.code == RT.compute
-        q = (8 if RT.compute == N.F16 else 2) if same else 4
+        q = (8 if RT.compute == N.F16 else 4) if same else 4       # whole 16-byte quarters of a 64-byte chunk (csrc/conv_mfma.hip: fast)
         if a.ptr % 16 or (a.ld * es) % 16 or a.C % q or not (same or (RT.compute == N.F16 and a.dtype == torch.float32)):
             return False
     return True
