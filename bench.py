@@ -83,7 +83,8 @@ def launch_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else None))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    for ln in out.decode().splitlines():          # stdout carries exactly the JSON line; anything else a library printed goes to stderr
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     if any(codes):
         sys.exit(f"bench.py: rank exit codes {codes}")

@@ -39,6 +39,45 @@ class ConvDesc(Structure):
     ]
 
 
+class ScanGc(Structure):
+    _fields_ = [("y", c_void_p), ("mu", c_void_p), ("scale", c_void_p),
+                ("y_ld", c_int32), ("mu_ld", c_int32), ("scale_ld", c_int32), ("dtype", c_int32),
+                ("table", c_void_p), ("levels", c_int32),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32),
+                ("symbols", c_void_p), ("indexes", c_void_p),
+                ("y_hat", c_void_p), ("y_hat_ld", c_int32)]
+
+
+class ScanEb(Structure):
+    _fields_ = [("z", c_void_p), ("z_ld", c_int32), ("dtype", c_int32),
+                ("params", c_void_p),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("mode", c_int32),
+                ("symbols", c_void_p),
+                ("z_hat", c_void_p), ("z_hat_ld", c_int32),
+                ("lik", c_void_p), ("lik_ld", c_int32)]
+
+
+class _Operand(Structure):
+    _fields_ = [("ptr", c_void_p), ("ld", c_int32), ("dtype", c_int32)]
+
+
+class ScanEw(Structure):
+    _fields_ = [("op", c_int32), ("C", c_int32), ("n_pix", c_int64),
+                ("a", _Operand), ("b", _Operand), ("c", _Operand), ("d", _Operand), ("e", _Operand),
+                ("out", c_void_p), ("out_ld", c_int32), ("out_dtype", c_int32)]
+
+
+class _ScanU(ctypes.Union):
+    _fields_ = [("conv", ConvDesc), ("gc", ScanGc), ("eb", ScanEb), ("ew", ScanEw)]
+
+
+class ScanOp(Structure):
+    _fields_ = [("kind", c_int32), ("reserved", c_int32), ("u", _ScanU)]
+
+
+SCAN_CONV, SCAN_GC_QUANTIZE, SCAN_GC_DEQUANTIZE, SCAN_EB_PROCESS, SCAN_EB_DEQUANTIZE, SCAN_ELTWISE = 0, 1, 2, 3, 4, 5
+
+
 class Operand(Structure):
     _fields_ = [("ptr", c_void_p), ("ld", c_int32), ("dtype", c_int32)]
 
@@ -58,6 +97,7 @@ SIGNATURES = {
     "dsvc_conv_pack_weights": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "dsvc_deconv5x5s2_to_conv3x3": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "dsvc_conv2d": (c_int, [c_void_p, POINTER(ConvDesc)]),
+    "dsvc_entropy_scan_step": (c_int, [c_void_p, c_void_p, c_int32]),
     "dsvc_warp_bilinear_border": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                           c_int32, c_int32, c_int32, c_int32]),
     "dsvc_upsample2x_bilinear": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float]),

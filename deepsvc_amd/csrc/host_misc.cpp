@@ -141,3 +141,53 @@ extern "C" int dsvc_deconv5x5s2_to_conv3x3(const float* wt, const float* bias, i
             }
     return DSVC_OK;
 }
+
+
+// ---- one scan step = a recorded launch sequence, issued without returning to the host language (include/dsvc.h) ----------------
+extern "C" int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int32_t n_ops) {
+    DSVC_REQUIRE(ops != nullptr && n_ops >= 0, "entropy_scan_step: null op list");
+    for (int32_t i = 0; i < n_ops; ++i) {
+        const dsvc_scan_op& o = ops[i];
+        int rc = DSVC_E_ARG;
+        switch (o.kind) {
+            case DSVC_SCAN_CONV: rc = dsvc_conv2d(stream, &o.u.conv); break;
+            case DSVC_SCAN_GC_QUANTIZE: {
+                const dsvc_scan_gc& g = o.u.gc;
+                rc = dsvc_gc_quantize(stream, g.y, g.y_ld, g.mu, g.mu_ld, g.scale, g.scale_ld, g.dtype, g.table, g.levels, g.B, g.H, g.W, g.C,
+                                      g.symbols, g.indexes, g.y_hat, g.y_hat_ld);
+                break;
+            }
+            case DSVC_SCAN_GC_DEQUANTIZE: {
+                const dsvc_scan_gc& g = o.u.gc;
+                rc = dsvc_gc_dequantize(stream, g.symbols, g.mu, g.mu_ld, g.dtype, g.B, g.H, g.W, g.C, g.y_hat, g.y_hat_ld);
+                break;
+            }
+            case DSVC_SCAN_EB_PROCESS: {
+                const dsvc_scan_eb& e = o.u.eb;
+                rc = dsvc_eb_process(stream, e.z, e.z_ld, e.dtype, e.params, e.B, e.H, e.W, e.C, e.mode, e.symbols, e.z_hat, e.z_hat_ld, e.lik, e.lik_ld);
+                break;
+            }
+            case DSVC_SCAN_EB_DEQUANTIZE: {
+                const dsvc_scan_eb& e = o.u.eb;
+                rc = dsvc_eb_dequantize(stream, e.symbols, e.params, e.dtype, e.B, e.H, e.W, e.C, e.z_hat, e.z_hat_ld);
+                break;
+            }
+            case DSVC_SCAN_ELTWISE: {
+                const dsvc_scan_ew& w = o.u.ew;
+                auto opt = [](const dsvc_operand& x) { return x.ptr ? &x : nullptr; };
+                rc = dsvc_eltwise(stream, w.op, w.n_pix, w.C, opt(w.a), opt(w.b), opt(w.c), opt(w.d), opt(w.e), w.out, w.out_ld, w.out_dtype);
+                break;
+            }
+            default:
+                dsvc_set_error("entropy_scan_step: op %d has unknown kind %d", i, o.kind);
+                return DSVC_E_ARG;
+        }
+        if (rc != DSVC_OK) {
+            char inner[400];
+            snprintf(inner, sizeof(inner), "%s", dsvc_last_error());
+            dsvc_set_error("entropy_scan_step: op %d of %d (kind %d) failed: %s", i, n_ops, o.kind, inner);
+            return rc;
+        }
+    }
+    return DSVC_OK;
+}

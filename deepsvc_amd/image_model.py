@@ -101,7 +101,7 @@ class _ScanPlan:
 
     def __init__(self, codec, B, h, w, device):
         Nc, Mc, d = codec.N, codec.M, codec.slice_depth          # hyper-latent z: N channels; latent y: M channels
-        self.device, self.epoch, self.graphs = device, -1, {}
+        self.device, self.epoch, self.graphs, self.programs = device, -1, {}, {}
         act = lambda H, W, C: ops.new_act(B, H, W, C, F32, device)
         self.y, self.y_hat = act(h, w, Mc), act(h, w, Mc)
         # (means, scales) and every slice's (mu_i, sigma_i) sit in ONE buffer each, pair after pair: the mean and the scale
@@ -376,18 +376,34 @@ class ChannelSplitICIP2020ResB(nn.Module):
             if plan is None:
                 plan = plans[key] = _ScanPlan(self, B, h, w, device)
             plan.graphs.clear()                  # weights were repacked since capture: the graphs hold stale pointers
+            plan.programs.clear()                # ... and so do the recorded scan steps
             plan.epoch = self._epoch_ref()[0]
         return plan
 
     def _step(self, plan, key, fn):
-        """Run one scan segment: replay its HIP graph when one has been captured for the current weights, else eagerly.
-        A segment is a fixed sequence of ~20-90 tiny launches on static buffers with no host interaction -- exactly what
-        a graph is for: the CPU cost per segment drops from ~30 us per launch to one graph launch."""
-        g = plan.graphs.get(key) if ops.USE_GRAPHS[0] and plan.epoch == self._epoch_ref()[0] else None
+        """Run one scan segment (the encoder scan, or one dependency level of the decoder scan): a fixed sequence of ~20-90
+        tiny launches on static buffers with no host interaction.
+          * first execution: issued launch by launch from here while `ops.ScanRecorder` records the sequence;
+          * afterwards: ONE call into the C library replays it (include/dsvc.h: dsvc_entropy_scan_step) -- no Python between
+            the launches;
+          * once captured (capture_scan_graphs), the same sequence is replayed as a HIP graph: the CPU cost per segment drops
+            from ~30 us per launch to one graph launch."""
+        valid = plan.epoch == self._epoch_ref()[0]
+        g = plan.graphs.get(key) if ops.USE_GRAPHS[0] and valid else None
         if g is not None:
             g.replay()
-        else:
+            return
+        if not (ops.SCAN_STEP[0] and valid) or ops.USE_FORKS[0]:
             fn()
+            return
+        prog = plan.programs.get(key)
+        if prog is None:
+            with ops.ScanRecorder() as rec:
+                fn()                              # executed AND recorded
+            if rec.poisoned is None and self._epoch_ref()[0] == plan.epoch:      # nothing was (re)packed while recording
+                plan.programs[key] = ops.ScanProgram(rec)
+        elif prog is not False:
+            prog.run()
 
     def scan_graphs_ready(self, B, h, w, device):
         key = (B, h, w, str(device), ops.RT.mode)
@@ -411,16 +427,24 @@ class ChannelSplitICIP2020ResB(nn.Module):
             t.zero_()
         ws.y.buf.zero_()
         epoch = self._epoch_ref()[0]
-        for fn in steps.values():                 # eager warm-up on dummy data: packs weights, sets kernel attributes
-            fn()
+        use_graphs, ops.USE_GRAPHS[0] = ops.USE_GRAPHS[0], False
+        try:
+            for key, fn in steps.items():         # eager warm-up on dummy data: packs weights, sets kernel attributes, records
+                self._step(ws, key, fn)           # the segment as a scan step (ops.ScanProgram)
+        finally:
+            ops.USE_GRAPHS[0] = use_graphs
         torch.cuda.synchronize(device)
         if self._epoch_ref()[0] != epoch:            # something was packed just now: pointers may move again, retry later
             self._plan(B, h, w, device)
             return False
         for key, fn in steps.items():
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                fn()                              # recorded, not executed
+            prog = ws.programs.get(key)
+            with torch.cuda.graph(g):             # recorded, not executed: the scan step's launches become the graph's nodes
+                if prog:
+                    prog.run()
+                else:
+                    fn()
             ws.graphs[key] = g
         torch.cuda.synchronize(device)
         return True

@@ -63,6 +63,61 @@ S2D = [_os.environ.get("DSVC_NO_S2D", "") == ""]       # conv5x5/s2 through the 
 USE_FORKS = [_os.environ.get("DSVC_FORKS", "") != ""]   # opt-in: measured 17.15 vs 17.6 fps (event edges cost more than the overlap)
 
 
+# --------------------------------------------------------------------------------------------
+# scan steps: a launch sequence recorded once, replayed by ONE C call (include/dsvc.h: dsvc_entropy_scan_step)
+# --------------------------------------------------------------------------------------------
+SCAN_STEP = [_os.environ.get("DSVC_NO_SCAN_STEP", "") == ""]
+_recording = _threading.local()
+
+
+class ScanRecorder:
+    """While active on this thread, every conv / entropy / element-wise launch issued through this module is ALSO appended to
+    `ops` as a dsvc_scan_op, and every tensor it touches (including the temporaries new_act hands out) is kept alive in
+    `keep`; an op that has no scan-op form poisons the recording (the caller then keeps issuing the launches itself)."""
+
+    def __init__(self):
+        self.ops, self.keep, self.poisoned = [], [], None
+
+    def __enter__(self):
+        self.prev = getattr(_recording, "cur", None)
+        _recording.cur = self
+        return self
+
+    def __exit__(self, *exc):
+        _recording.cur = self.prev
+        return False
+
+    def add(self, kind, field, struct, keep):
+        op = N.ScanOp()
+        op.kind = kind
+        ctypes.memmove(ctypes.addressof(getattr(op.u, field)), ctypes.addressof(struct), ctypes.sizeof(struct))
+        self.ops.append(op)
+        self.keep.extend(k for k in keep if k is not None)
+
+
+def _rec():
+    return getattr(_recording, "cur", None)
+
+
+def poison_recording(why):
+    r = _rec()
+    if r is not None and r.poisoned is None:
+        r.poisoned = why
+
+
+class ScanProgram:
+    """A frozen recording: replay = one call into the C library."""
+
+    def __init__(self, recorder):
+        assert recorder.poisoned is None
+        self.n = len(recorder.ops)
+        self.arr = (N.ScanOp * max(self.n, 1))(*recorder.ops)
+        self.keep = recorder.keep
+
+    def run(self):
+        N.check(N.lib().dsvc_entropy_scan_step(_stream(), ctypes.addressof(self.arr), self.n), "entropy_scan_step")
+
+
 def set_option(key, value):
     """Kernel-selection switch of the conv dispatcher (include/dsvc.h: dsvc_set_option); returns the previous value."""
     return N.check(N.lib().dsvc_set_option(key.encode(), int(value)), "set_option")
@@ -149,7 +204,11 @@ class Act:
 
 def new_act(B, H, W, C, dtype=None, device=None, ld=None):
     ld = C if ld is None else ld
-    return Act(torch.empty((B, H, W, ld), dtype=dtype or RT.storage, device=device), 0, C)
+    a = Act(torch.empty((B, H, W, ld), dtype=dtype or RT.storage, device=device), 0, C)
+    r = getattr(_recording, "cur", None)
+    if r is not None:            # a temporary of a recorded scan step: replays write to this address, so it must stay allocated
+        r.keep.append(a.buf)
+    return a
 
 
 def to_act(x, dtype=None):
@@ -320,6 +379,9 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
         d.res2, d.res2_ld, d.res2_dtype = res2.ptr, res2.ld, res2.code
     d.shuffle = shuffle
     d.out, d.out_ld, d.out_dtype = out.ptr, out.ld, out.code
+    r = _rec()
+    if r is not None:
+        r.add(N.SCAN_CONV, "conv", d, [pc, out.buf, gate, post] + [a.buf for a in inputs] + [x.buf for x in (res1, res2) if x is not None])
     prof = PROFILE
     if prof is not None and prof["match"](pc, x0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -361,6 +423,9 @@ def _conv2d_items(pc, inputs, out, items, *, act, pre_act, slope, res1, shuffle,
         d.res1, d.res1_ld, d.res1_dtype = res1.ptr, res1.ld, res1.code
     d.shuffle = shuffle
     d.out, d.out_ld, d.out_dtype = out.ptr, out.ld, out.code
+    r = _rec()
+    if r is not None:
+        r.add(N.SCAN_CONV, "conv", d, [pc, out.buf] + [a.buf for a in inputs] + ([res1.buf] if res1 is not None else []))
     N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d (items)")
     return out
 
@@ -380,6 +445,7 @@ def items_ok(acts):
 # resampling / layout / pointwise
 # --------------------------------------------------------------------------------------------
 def warp(x, flow, out=None):
+    poison_recording("warp")          # not a scan-step op
     assert flow.dtype == torch.float32 and flow.C == 2
     out = out or new_act(x.B, x.H, x.W, x.C, x.dtype, x.device)
     N.check(N.lib().dsvc_warp_bilinear_border(_stream(), x.ptr, x.ld, x.code, flow.ptr, flow.ld, out.ptr, out.ld, out.code,
@@ -388,6 +454,7 @@ def warp(x, flow, out=None):
 
 
 def upsample2x(x, scale=1.0, out=None):
+    poison_recording("upsample2x")          # not a scan-step op
     assert x.dtype == torch.float32
     out = out or new_act(x.B, 2 * x.H, 2 * x.W, x.C, torch.float32, x.device)
     N.check(N.lib().dsvc_upsample2x_bilinear(_stream(), x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, x.C, float(scale)), "upsample2x")
@@ -395,6 +462,7 @@ def upsample2x(x, scale=1.0, out=None):
 
 
 def pool2x2(x, mode, out=None):
+    poison_recording("pool2x2")          # not a scan-step op
     out = out or new_act(x.B, x.H // 2, x.W // 2, x.C, x.dtype, x.device)
     assert out.dtype == x.dtype
     N.check(N.lib().dsvc_pool2x2(_stream(), 0 if mode == "avg" else 1, x.ptr, x.ld, out.ptr, out.ld, x.code, x.B, x.H, x.W, x.C), "pool2x2")
@@ -402,6 +470,7 @@ def pool2x2(x, mode, out=None):
 
 
 def pixel_shuffle_nchw(x_nchw, r, out=None, dtype=None):
+    poison_recording("pixel_shuffle_nchw")          # not a scan-step op
     _require_gpu(x_nchw)
     x = x_nchw.to(torch.float32).contiguous()
     B, C, H, W = x.shape
@@ -417,12 +486,23 @@ def _op(a):
 
 def eltwise(op, a, b=None, c=None, d=None, e=None, out=None, out_dtype=None):
     out = out or new_act(a.B, a.H, a.W, a.C, out_dtype or a.dtype, a.device)
+    r = _rec()
+    if r is not None:
+        w = N.ScanEw()
+        w.op, w.C, w.n_pix = op, a.C, a.npix
+        for name, x in (("a", a), ("b", b), ("c", c), ("d", d), ("e", e)):
+            if x is not None:
+                o = getattr(w, name)
+                o.ptr, o.ld, o.dtype = x.ptr, x.ld, x.code
+        w.out, w.out_ld, w.out_dtype = out.ptr, out.ld, out.code
+        r.add(N.SCAN_ELTWISE, "ew", w, [out.buf] + [x.buf for x in (a, b, c, d, e) if x is not None])
     N.check(N.lib().dsvc_eltwise(_stream(), op, a.npix, a.C, _op(a), _op(b), _op(c), _op(d), _op(e), out.ptr, out.ld, out.code), "eltwise")
     return out
 
 
 def se_gate(x, w1, w2):
     """SELayer gate [B, C] fp32 for activation x (w1 [C/r, C], w2 [C, C/r] device fp32)."""
+    poison_recording("se_gate")          # not a scan-step op
     L = N.lib()
     ws = torch.empty(L.dsvc_se_workspace_floats(x.B, x.C), dtype=torch.float32, device=x.device)
     gate = torch.empty((x.B, x.C), dtype=torch.float32, device=x.device)
@@ -433,6 +513,7 @@ def se_gate(x, w1, w2):
 
 def refine_aggregate(x, rx, rs, mean=True, relu=False):
     """RefineNet1's aggregation (include/dsvc.h: dsvc_refine_aggregate): x, rx [1,H,W,C] fp32 Acts, rs [L,H,W,C] fp32 Act."""
+    poison_recording("refine_aggregate")          # not a scan-step op
     for a in (x, rx, rs):
         _require_gpu(a.buf)
         assert a.dtype == torch.float32, "refine_aggregate works on fp32 features"
@@ -444,6 +525,7 @@ def refine_aggregate(x, rx, rs, mean=True, relu=False):
 
 def reduce(mode, a, b=None):
     """mode: 'sum' | 'sumlog' | 'sqdiff' -> 0-dim fp64 device tensor."""
+    poison_recording("reduce")          # not a scan-step op
     L = N.lib()
     ws = torch.empty(L.dsvc_reduce_workspace_floats(), dtype=torch.float32, device=a.device)
     out = torch.empty((), dtype=torch.float64, device=a.device)
@@ -481,6 +563,18 @@ def gc_quantize(y, mu, scale, table, want_symbols=True, want_indexes=True, y_hat
     sym = (sym_out if sym_out is not None else torch.empty(n, dtype=torch.int32, device=dev)) if want_symbols else None
     idx = (idx_out if idx_out is not None else torch.empty(n, dtype=torch.int32, device=dev)) if want_indexes else None
     assert (sym is None or (sym.numel() == n and sym.dtype == torch.int32)) and (idx is None or (idx.numel() == n and idx.dtype == torch.int32))
+    r = _rec()
+    if r is not None:
+        g = N.ScanGc()
+        g.y, g.y_ld = (None, 0) if y is None else (y.ptr, y.ld)
+        g.mu, g.mu_ld = mu.ptr, mu.ld
+        g.scale, g.scale_ld = (None, 0) if scale is None else (scale.ptr, scale.ld)
+        g.dtype, g.table, g.levels = mu.code, table.data_ptr(), table.numel()
+        g.B, g.H, g.W, g.C = B, H, W, C
+        g.symbols = None if sym is None else sym.data_ptr()
+        g.indexes = None if idx is None else idx.data_ptr()
+        g.y_hat, g.y_hat_ld = (None, 0) if y_hat is None else (y_hat.ptr, y_hat.ld)
+        r.add(N.SCAN_GC_QUANTIZE, "gc", g, [table, sym, idx, mu.buf] + [x.buf for x in (y, scale, y_hat) if x is not None])
     N.check(N.lib().dsvc_gc_quantize(_stream(), None if y is None else y.ptr, 0 if y is None else y.ld, mu.ptr, mu.ld,
                                      None if scale is None else scale.ptr, 0 if scale is None else scale.ld, mu.code,
                                      table.data_ptr(), table.numel(), B, H, W, C,
@@ -490,12 +584,20 @@ def gc_quantize(y, mu, scale, table, want_symbols=True, want_indexes=True, y_hat
 
 
 def gc_dequantize(symbols, mu, y_hat):
+    r = _rec()
+    if r is not None:
+        g = N.ScanGc()
+        g.symbols, g.mu, g.mu_ld, g.dtype = symbols.data_ptr(), mu.ptr, mu.ld, mu.code
+        g.B, g.H, g.W, g.C = mu.B, mu.H, mu.W, mu.C
+        g.y_hat, g.y_hat_ld = y_hat.ptr, y_hat.ld
+        r.add(N.SCAN_GC_DEQUANTIZE, "gc", g, [symbols, mu.buf, y_hat.buf])
     N.check(N.lib().dsvc_gc_dequantize(_stream(), symbols.data_ptr(), mu.ptr, mu.ld, mu.code, mu.B, mu.H, mu.W, mu.C,
                                        y_hat.ptr, y_hat.ld), "gc_dequantize")
     return y_hat
 
 
 def gc_likelihood(y, mu, scale, y_hat=None, lik=None):
+    poison_recording("gc_likelihood")          # not a scan-step op
     N.check(N.lib().dsvc_gc_likelihood(_stream(), y.ptr, y.ld, mu.ptr, mu.ld, scale.ptr, scale.ld, mu.code, mu.npix, mu.C,
                                        None if y_hat is None else y_hat.ptr, 0 if y_hat is None else y_hat.ld,
                                        None if lik is None else lik.ptr, 0 if lik is None else lik.ld), "gc_likelihood")
@@ -505,6 +607,15 @@ def eb_process(z, params, symbols=False, z_hat=None, lik=None, sym_out=None):
     B, H, W, C = z.B, z.H, z.W, z.C
     sym = (sym_out if sym_out is not None else torch.empty(B * C * H * W, dtype=torch.int32, device=z.device)) if symbols else None
     mode = (1 if symbols else 0) | (2 if z_hat is not None else 0) | (4 if lik is not None else 0)
+    r = _rec()
+    if r is not None:
+        e = N.ScanEb()
+        e.z, e.z_ld, e.dtype, e.params = z.ptr, z.ld, z.code, params.data_ptr()
+        e.B, e.H, e.W, e.C, e.mode = B, H, W, C, mode
+        e.symbols = None if sym is None else sym.data_ptr()
+        e.z_hat, e.z_hat_ld = (None, 0) if z_hat is None else (z_hat.ptr, z_hat.ld)
+        e.lik, e.lik_ld = (None, 0) if lik is None else (lik.ptr, lik.ld)
+        r.add(N.SCAN_EB_PROCESS, "eb", e, [params, sym, z.buf] + [x.buf for x in (z_hat, lik) if x is not None])
     N.check(N.lib().dsvc_eb_process(_stream(), z.ptr, z.ld, z.code, params.data_ptr(), B, H, W, C, mode,
                                     None if sym is None else sym.data_ptr(),
                                     None if z_hat is None else z_hat.ptr, 0 if z_hat is None else z_hat.ld,
@@ -513,6 +624,13 @@ def eb_process(z, params, symbols=False, z_hat=None, lik=None, sym_out=None):
 
 
 def eb_dequantize(symbols, params, z_hat):
+    r = _rec()
+    if r is not None:
+        e = N.ScanEb()
+        e.symbols, e.params, e.dtype = symbols.data_ptr(), params.data_ptr(), z_hat.code
+        e.B, e.H, e.W, e.C = z_hat.B, z_hat.H, z_hat.W, z_hat.C
+        e.z_hat, e.z_hat_ld = z_hat.ptr, z_hat.ld
+        r.add(N.SCAN_EB_DEQUANTIZE, "eb", e, [symbols, params, z_hat.buf])
     N.check(N.lib().dsvc_eb_dequantize(_stream(), symbols.data_ptr(), params.data_ptr(), z_hat.code, z_hat.B, z_hat.H, z_hat.W,
                                        z_hat.C, z_hat.ptr, z_hat.ld), "eb_dequantize")
     return z_hat

@@ -232,6 +232,50 @@ int dsvc_eb_process(void* stream, const void* z, int32_t z_ld, int32_t dtype, co
 int dsvc_eb_dequantize(void* stream, const int32_t* symbols, const float* params, int32_t dtype,
                        int32_t B, int32_t H, int32_t W, int32_t C, void* z_hat, int32_t z_hat_ld);
 
+/* One step of the channel-conditional entropy scan as ONE call (dsvc_entropy_scan_step; reference loops
+ * image_model.py:226-251 (encoder) and :276-297 (decoder), whose every iteration returns to Python -- and to the host with
+ * .tolist() -- between its ~11 small convs).  A step is the fixed launch sequence of one dependency level of the scan over a
+ * codec's static workspace: the parameter nets (cc_mean || cc_scale of every slice of the level as batch items of one conv per
+ * layer), build_indexes (+ quantise on the encoder side / dequantise on the decoder side) and the latent-residual-prediction
+ * stacks -- or the whole encoder scan, hyper-analysis included, since the encoder needs no host round trip at all.
+ * The caller describes the sequence ONCE as an array of ops (pointers into buffers it keeps alive) and replays it per frame;
+ * the library issues the launches back to back on `stream` (stream-ordered, no host synchronisation, capturable into a HIP
+ * graph).  Results are those of issuing the same ops through dsvc_conv2d / dsvc_gc_* / dsvc_eb_* one by one.
+ * On failure returns the failing op's error code; dsvc_last_error() names the op index. */
+#define DSVC_SCAN_CONV 0            /* u.conv: dsvc_conv2d */
+#define DSVC_SCAN_GC_QUANTIZE 1     /* u.gc:   dsvc_gc_quantize (symbols / indexes / y_hat each optional) */
+#define DSVC_SCAN_GC_DEQUANTIZE 2   /* u.gc:   dsvc_gc_dequantize (symbols, mu -> y_hat) */
+#define DSVC_SCAN_EB_PROCESS 3      /* u.eb:   dsvc_eb_process */
+#define DSVC_SCAN_EB_DEQUANTIZE 4   /* u.eb:   dsvc_eb_dequantize */
+#define DSVC_SCAN_ELTWISE 5         /* u.ew:   dsvc_eltwise (f16 mode packs small fp32 support slices for the conv's fast staging path) */
+typedef struct dsvc_scan_gc {
+    const void* y; const void* mu; const void* scale;
+    int32_t y_ld, mu_ld, scale_ld, dtype;
+    const float* table; int32_t levels;
+    int32_t B, H, W, C;
+    int32_t* symbols; int32_t* indexes;
+    void* y_hat; int32_t y_hat_ld;
+} dsvc_scan_gc;
+typedef struct dsvc_scan_eb {
+    const void* z; int32_t z_ld, dtype;
+    const float* params;
+    int32_t B, H, W, C, mode;
+    int32_t* symbols;
+    void* z_hat; int32_t z_hat_ld;
+    float* lik; int32_t lik_ld;
+} dsvc_scan_eb;
+typedef struct dsvc_scan_ew {
+    int32_t op, C; int64_t n_pix;
+    dsvc_operand a, b, c, d, e;      /* an absent operand has ptr == NULL */
+    void* out; int32_t out_ld, out_dtype;
+} dsvc_scan_ew;
+typedef struct dsvc_scan_op {
+    int32_t kind;           /* DSVC_SCAN_* */
+    int32_t reserved;
+    union { dsvc_conv_desc conv; dsvc_scan_gc gc; dsvc_scan_eb eb; dsvc_scan_ew ew; } u;
+} dsvc_scan_op;
+int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int32_t n_ops);
+
 /* ------------------------------------------------------------------------------------------
  * HOST: integer CDF construction and the range coder (compressai 1.2.1 _CXX / ans; Appendix A.4/A.5)
  * ------------------------------------------------------------------------------------------ */
