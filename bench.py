@@ -289,7 +289,7 @@ def main():
 
     side = not args.no_side_legs
     lanes1 = parity = deltas = None
-    durs_own = durs_shared if args.lanes == 1 else None
+    durs_own = durs_shared if (args.lanes == 1 or not side) else None     # without the lanes1 leg only the time-shared durations exist
     if side and args.lanes > 1:
         # ---- the same mode, ONE GOP in flight: the kernel's own durations ----
         for L in lanes:
@@ -365,8 +365,9 @@ def main():
         if roof is not None:
             roof["traffic"] = traffic
             roof["measured_in"] = "lanes1 leg (one GOP in flight): HIP events on the launch stream around every launch of this shape" if args.lanes > 1 and side \
-                else "timed region (one GOP in flight): HIP events on the launch stream around every launch of this shape"
-            if args.lanes > 1 and durs_shared:
+                else ("timed region (one GOP in flight): HIP events on the launch stream around every launch of this shape" if args.lanes == 1 else
+                      f"timed region with {args.lanes} lanes in flight (--no-side-legs): durations are TIME-SHARED with the other lanes' kernels, not the kernel's own cost")
+            if args.lanes > 1 and side and durs_shared:
                 ts = sum(durs_shared) / len(durs_shared)
                 roof["timeshared_avg_ms"] = ts
                 roof["timeshared_frac"] = conv_flop / (ts * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision]
