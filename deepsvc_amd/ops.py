@@ -389,6 +389,7 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
         N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
         e1.record()
         prof["pairs"].append((e0, e1))
+        prof.setdefault("nres", []).append(int(res1 is not None) + int(res2 is not None))
         return out
     N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
     return out
