@@ -274,6 +274,7 @@ def main():
         avg_ms = sum(durs) / len(durs)
         achieved = conv_flop / (avg_ms * 1e-3) / 1e12
         esz = 2 if precision == "f16" else 4
+        alg_bytes = (2.0 + nres[0]) * H_pad * W_pad * 64 * esz       # input + output + the residual operand(s), launch-weighted mean
         r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision],
              "traffic": None,
              "kernel": f"3x3 s1 64->64 conv @{H_pad}x{W_pad}, all epilogue variants ({'conv3x3_pp_kernel' if precision == 'f16' else 'conv_mfma_kernel'})",

@@ -40,6 +40,17 @@ namespace {
 
 constexpr int PP_TH = 8, PP_PW = 34, PP_NPATCH = (PP_TH + 2) * PP_PW;   // 340 patch pixels
 constexpr int PP_PFV = (PP_NPATCH * 4 + 255) / 256;                     // 6 prefetch vectors per thread
+#ifndef PP_PF0_IN_S1
+#define PP_PF0_IN_S1 1
+#endif
+constexpr bool PF0_IN_S1 = PP_PF0_IN_S1 != 0;
+#ifndef PP_MIN_BLOCKS
+#define PP_MIN_BLOCKS 2
+#endif
+#ifndef PP_RES_IN_S1
+#define PP_RES_IN_S1 0
+#endif
+constexpr bool RES_IN_S1 = PP_RES_IN_S1 != 0;
 
 __device__ __forceinline__ void buf_store16(rsrc_t r, unsigned off, uint4 v) {
     v4u_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
@@ -74,10 +85,14 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
 // B-operand fragment of k-block kb of a 32x32x16 MFMA -- so the tile feeds 2 x 4 MFMAs per row against weight fragments
 // read from LDS and the intermediate never leaves registers (it is rounded to f16 as a stored tensor would be).
 template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false>
-__global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
+__global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
                                                               float pre_slope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTN = NT * 32, MTW = 2;
+    // where the next tile's chunk-0 loads are issued: in the S1 phase for the variants whose E phase also issues residual loads
+    // (same-box A/B, tools/bench_pp.py: + residual 212 -> 194 us, two residuals 262 -> 243, fused tail 232 -> 218), in the E phase
+    // for the others (plain 193 -> 200 us when moved)
+    constexpr bool PF0S1 = PF0_IN_S1 && HAS_R1 && NCH == 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef PP_GROUP_PARITY
@@ -263,8 +278,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
     load_chunk(cur, 0, pf0);
     store_chunk(pf0);
     if constexpr (NCH == 2) load_chunk(cur, 1, pf1);
-    load_chunk(nxt, 0, pf0);
-    if constexpr (HAS_R1) load_res(cur, tile_of(0) < ntiles);
+    if constexpr (!PF0S1) load_chunk(nxt, 0, pf0);
+    if constexpr (HAS_R1 && !(RES_IN_S1 && NCH == 2)) load_res(cur, tile_of(0) < ntiles);
     lds_barrier();                       // weights, bias and both groups' first patches are in place
     if (g) lds_barrier();                // group 1 runs one phase behind group 0
 
@@ -277,6 +292,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
             // ---- S1 (+ prefetch: next tile's chunk 1) ----
             store_chunk(pf1);
             load_chunk(nxt, 1, pf1);
+            // the next tile's chunk 0 is requested HERE, not in the E phase: a vector-memory instruction costs 150-250 cycles to
+            // issue beside the partner group's MFMA + LDS stream, and the E phase (8 stores, 8-12 residual loads) is the longest
+            // phase while this one is the shortest; the data is consumed at the end of this iteration's E phase (M1 + E later)
+            if constexpr (PF0S1) load_chunk(nxt, 0, pf0);
+            if constexpr (HAS_R1 && RES_IN_S1) load_res(cur, valid);
             lds_barrier();
             // ---- M1 ----
             mfma_phase(1, false);
@@ -404,8 +424,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp_kernel(const ConvParams p, 
         store_chunk(pf0);
         cur = nxt;
         nxt = tile_origin(min(tile_of(k + 2), ntiles - 1));
-        load_chunk(nxt, 0, pf0);
-        if constexpr (HAS_R1) load_res(cur, tile_of(k + 1) < ntiles);
+        if constexpr (!PF0S1) load_chunk(nxt, 0, pf0);
+        if constexpr (HAS_R1 && !(RES_IN_S1 && NCH == 2)) load_res(cur, tile_of(k + 1) < ntiles);
         lds_barrier();
     }
     if (!g) lds_barrier();               // matches group 1's leading barrier
