@@ -89,10 +89,13 @@ __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const Co
                                                               float pre_slope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTN = NT * 32, MTW = 2;
-    // where the next tile's chunk-0 loads are issued: in the S1 phase for the variants whose E phase also issues residual loads
-    // (same-box A/B, tools/bench_pp.py: + residual 212 -> 194 us, two residuals 262 -> 243, fused tail 232 -> 218), in the E phase
-    // for the others (plain 193 -> 200 us when moved)
-    constexpr bool PF0S1 = PF0_IN_S1 && HAS_R1 && NCH == 2;
+    // where the next tile's chunk-0 loads are issued: in the S1 phase (the shortest one) instead of the E phase (the longest: 8 stores
+    // and, with a residual, 8 more loads -- a vector-memory instruction costs 150-250 cycles to issue beside the partner group's
+    // MFMA + LDS stream).  Same-box A/B on an idle GPU (tools/bench_pp.py): + residual 212 -> 194 us, two residuals 262 -> 243,
+    // fused tail 232 -> 218, plain 193 -> 200; inside the frame (bench.py --lanes 1, rocprofv3): + residual 218 -> 191 us, fused
+    // tail 142 -> 124, PMC traffic of the residual variants 1.24x -> 1.07x algorithmic, all variants moved: another -1 % on the
+    // launch average.  NCH == 1 variants have no S1 phase.
+    constexpr bool PF0S1 = PF0_IN_S1 && NCH == 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef PP_GROUP_PARITY
