@@ -47,6 +47,12 @@ constexpr bool PF0_IN_S1 = PP_PF0_IN_S1 != 0;
 #ifndef PP_MIN_BLOCKS
 #define PP_MIN_BLOCKS 2
 #endif
+#ifndef PP_VMEM_PRIO
+#define PP_VMEM_PRIO 0
+#endif
+#ifndef PP_M_PRIO
+#define PP_M_PRIO 3
+#endif
 #ifndef PP_RES_IN_S1
 #define PP_RES_IN_S1 0
 #endif
@@ -163,12 +169,14 @@ __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const Co
         const unsigned ldb = (unsigned)sg.ld * 2, cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
         const bool cok = (ch - sg.chunk0) * 32 + q * 8 < sg.C;             // short chunk (C % 8 == 0): the tail reads zeros
         const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;        // scalar; negative only where inb is false
+        if (PP_VMEM_PRIO) __builtin_amdgcn_s_setprio(PP_VMEM_PRIO);
 #pragma unroll
         for (int j = 0; j < PP_PFV; ++j) {
             const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
             const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PP_PFV - 1 || last_ok) && cok;   // padding reads zeros
             pf[j] = buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));   // no select of offsets: that becomes an exec-mask branch per load
         }
+        if (PP_VMEM_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto store_chunk = [&](uint4 (&pf)[PP_PFV]) {
 #pragma unroll
@@ -209,7 +217,7 @@ __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const Co
         uint4 af[3][MTW], bf[3][NT];                 // fragments are read TWO k-steps ahead: one step (4 MFMAs = 128 cycles)
         read_frags(0, af[0], bf[0]);                // does not cover the ds_read latency while the other group also uses LDS
         read_frags(1, af[1], bf[1]);
-        __builtin_amdgcn_s_setprio(3);              // the SIMD's issue arbiter otherwise favours the older group-0 waves:
+        __builtin_amdgcn_s_setprio(PP_M_PRIO);      // the SIMD's issue arbiter otherwise favours the older group-0 waves:
 #pragma unroll                                      // their VALU-dense epilogue starved group 1's MFMAs (in-kernel stamps)
         for (int s2 = 0; s2 < 18; ++s2) {
             if (s2 + 2 < 18) read_frags(s2 + 2, af[(s2 + 2) % 3], bf[(s2 + 2) % 3]);
