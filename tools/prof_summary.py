@@ -36,13 +36,26 @@ def short(n):
 
 def by_shape(trace_csv, out_csv):
     agg = collections.OrderedDict()
+    rows = []
     with open(trace_csv) as f:
         for r in csv.DictReader(f):
             key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]), int(r["Workgroup_Size_X"]),
                    int(r["LDS_Block_Size"]), int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
-            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-            a = agg.setdefault(key, [0, 0.0, 1e30, 0.0])
-            a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+            rows.append((key, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    # conv3x3_pp_kernel is persistent: 256 workgroups at every image size, so name + grid do not separate its full-resolution
+    # launches (1088x1920) from the half-resolution ones of the UNets (544x960, a quarter of the work).  Their durations are
+    # bimodal (e.g. 41 vs 117 us); a launch shorter than 0.45 x the variant's 90th-percentile duration is labelled @1/2.
+    import statistics
+    pp = collections.defaultdict(list)
+    for key, d in rows:
+        if key[0].startswith("conv3x3_pp_kernel"):
+            pp[key].append(d)
+    thr = {k: 0.45 * statistics.quantiles(v, n=10)[-1] if len(v) >= 10 else 0.0 for k, v in pp.items()}
+    for key, d in rows:
+        if key in thr:
+            key = (key[0] + (" @1/2 res (by duration)" if d < thr[key] else " @1/1 res (by duration)"),) + key[1:]
+        a = agg.setdefault(key, [0, 0.0, 1e30, 0.0])
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
     tot = sum(a[1] for a in agg.values())
     with open(out_csv, "w", newline="") as f:
         w = csv.writer(f)
