@@ -80,7 +80,7 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))       # only rank 0 may write the line to stdout
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     for ln in out.decode().splitlines():          # stdout carries exactly the JSON line; anything else a library printed goes to stderr
