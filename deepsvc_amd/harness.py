@@ -40,7 +40,17 @@ def _msssim(a, b):
     return float(ms_ssim(a.contiguous(), b.contiguous(), 1.0))
 
 
-def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=None, msssim=False, overlap_coding=False):
+def process(frame255, inverse=False):
+    """test_video.py:176-190 `Process`: per-channel (v - mean) / std of a 0..255 RGB frame, channels returned in reversed order
+    (the semantic layer's input normalisation)."""
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    ch = [frame255[:, i:i + 1] for i in range(3)]
+    out = [c * s_ + m if inverse else (c - m) / s_ for c, m, s_ in zip(ch, mean, std)]
+    return torch.cat([out[2], out[1], out[0]], 1)
+
+
+def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=None, msssim=False, overlap_coding=False,
+             sm_layer=None, supp=None, sm_log=None):
     """Encode+decode one GOP.  frames[1:] are P-frames; frames[0] is the key frame: taken as already decoded when
     `i_model` is None (BASELINE.json configs 1-2), else coded with the I-frame codec `i_model` (`ICIP2020ResB`,
     test_video.py:296-312: compress -> decompress, the clamped reconstruction becomes the first reference) and reported
@@ -52,7 +62,13 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
     the encode clock `t_enc` stops only after both codings have been JOINED, so t_enc / t_dec mean what the reference's
     timers mean (test_video.py:340-351: strings exist when compress returns).  `overlap_coding=True` is the throughput mode:
     the strings are joined by whoever reads them first (the decoder), which overlaps the residual range coding with the
-    decoder's motion path -- t_enc then excludes, and t_dec includes, that coding time; t_enc + t_dec is the same either way."""
+    decoder's motion path -- t_enc then excludes, and t_dec includes, that coding time; t_enc + t_dec is the same either way.
+
+    `sm_layer` (a `semantic_layer.StudentLayer1`) makes the loop self-contained the way test_video.py:336-338 is: per P-frame
+    `sm, y = sm_layer(process(cur * 255), supp, mean=True, encode=True)` produces `sm_fea` (instead of `sm_feas[t]`), and the
+    support stack advances `supp = cat([supp, sm])[1:]`; `supp` is the initial support ([n,256,H/4,W/4] on the padded frame: in the
+    reference the teacher network's feature of the key frame, out of scope here).  Its (bpp, enct, dect) per frame are appended
+    to `sm_log` -- the `sm_rows` argument of `reference_results`."""
     sync = sync or (lambda: None)
     h, w = frames[0].shape[-2:]
     rows = []
@@ -71,7 +87,13 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
     feature = None
     for t in range(1, len(frames)):
         cur = pad(frames[t], 64)
-        sm = sm_feas[t]
+        if sm_layer is not None:
+            sm, _ = sm_layer(process(cur * 255.0), supp, mean=True, encode=True)            # test_video.py:336
+            supp = torch.cat([supp, sm], 0)[1:]                                             # :338
+            if sm_log is not None:
+                sm_log.append((float(sm_layer.bpp_loss) * (cur.shape[-2] * cur.shape[-1]) / (h * w), sm_layer.enct, sm_layer.dect))
+        else:
+            sm = sm_feas[t]
         sync(); t0 = time.perf_counter()
         mv_enc, res_enc = model.compress(ref, cur, sm, feature)
         if not overlap_coding:

@@ -145,3 +145,33 @@ def test_fcodec_f16_mode(oracle):
         assert abs(nb - no) <= 0.01 * no + 8 and e <= 5e-3
     finally:
         ops.set_precision("fp32")
+
+
+def test_self_contained_gop_with_semantic_layer():
+    """test_video.py:336-338 loop shape: every P-frame's `sm_fea` comes from the semantic layer's codec (stage 1 of
+    OursResNetStudentP) run on `process(cur * 255)` against a rolling support stack; its rate and times fill the semantic-layer
+    keys of the reference JSON.  Coding the GOP twice gives identical rows (deterministic, encoder / decoder lock-step)."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("f16")
+    try:
+        size, n = 128, 4
+        sm_layer = _make("f16")
+        p = synth.make_model("W0"); p.update(force=True); p = p.to(DEV)
+        frames = [f.to(DEV) for f in synth.make_frames(size, size, n)]
+        _, supp0 = synth.make_semantic_input(size, size, 0)
+        runs = []
+        for _ in range(2):
+            log = []
+            rows = harness.code_gop(p, frames, [None] * n, unit=7, sync=torch.cuda.synchronize, sm_layer=sm_layer, supp=supp0.to(DEV), sm_log=log)
+            runs.append(([r[:7] for r in rows], [l[0] for l in log]))
+            assert len(rows) == n - 1 and len(log) == n - 1 and all(l[0] > 0 and l[1] > 0 and l[2] > 0 for l in log)
+        assert runs[0] == runs[1]
+        res = harness.reference_results(torch.tensor(rows, dtype=torch.float64), sm_rows={7.0: log})
+        assert res["smbpp"][0] > 0 and abs(res["pbpp"][0] - (res["mvbpp"][0] + res["resbpp"][0] + res["smbpp"][0])) < 1e-12
+        assert abs(res["bpp2l"][0] - (res["mvbpp"][0] + res["smbpp"][0])) < 1e-12 and res["pent"][0] > res["sment"][0] > 0
+        # harness.process == test_video.py:176-190 (normalise channel i with (mean_i, std_i), return channels reversed)
+        x = torch.rand(1, 3, 8, 8) * 255
+        want = torch.cat([(x[:, 2:3] - 103.53) / 57.375, (x[:, 1:2] - 116.28) / 57.12, (x[:, 0:1] - 123.675) / 58.395], 1)
+        assert torch.allclose(harness.process(x), want)
+    finally:
+        ops.set_precision("fp32")
