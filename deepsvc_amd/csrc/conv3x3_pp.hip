@@ -36,6 +36,23 @@
 
 using namespace dsvc_conv;
 
+#ifdef DSVC_PP_PROBE
+// Build with DSVC_BUILD_DEFINES=-DDSVC_PP_PROBE to get, for wave 0 of each group of every workgroup, the shader-clock time
+// between barriers: [g*8 + 2*i] = work of the group's phase i (0: M0, 1: S1, 2: M1, 3: E+S0), [g*8 + 2*i + 1] = wait at the barrier
+// that ends it; [16] = iterations.  Stamps sit immediately before / after the workgroup barriers, where the LDS queue is
+// drained anyway (tools/pp_phase_probe.py).
+__device__ unsigned long long g_pp_phase[17];
+extern "C" int dsvc_dbg_pp_phase_read(unsigned long long* out17, int reset) {
+    if (hipMemcpyFromSymbol(out17, HIP_SYMBOL(g_pp_phase), sizeof(g_pp_phase)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[17] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pp_phase), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define PP_STAMP(v) { v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define PP_BARRIER(i) { unsigned long long tb_, ta_; PP_STAMP(tb_) lds_barrier(); PP_STAMP(ta_) ppw[i] += tb_ - t_last; ppb[i] += ta_ - tb_; t_last = ta_; }
+#else
+#define PP_BARRIER(i) lds_barrier();
+#endif
+
 namespace {
 
 constexpr int PP_TH = 8, PP_PW = 34, PP_NPATCH = (PP_TH + 2) * PP_PW;   // 340 patch pixels
@@ -52,6 +69,9 @@ constexpr bool PF0_IN_S1 = PP_PF0_IN_S1 != 0;
 #endif
 #ifndef PP_M_PRIO
 #define PP_M_PRIO 3
+#endif
+#ifndef PP_RES_SPLIT
+#define PP_RES_SPLIT 0
 #endif
 #ifndef PP_RES_IN_S1
 #define PP_RES_IN_S1 0
@@ -255,9 +275,9 @@ __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const Co
         return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + 32 * (r >> 4) + 16 * h) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
     };
     uint4 res[MTW * NT * 2];
-    auto load_res = [&](const TileOrg& t, bool valid) {
+    auto load_res = [&](const TileOrg& t, bool valid, int m0 = 0, int m1 = MTW) {
 #pragma unroll
-        for (int m = 0; m < MTW; ++m)
+        for (int m = m0; m < m1; ++m)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const unsigned base = row_off(t, m, p.res1_ld, valid, half);
@@ -290,15 +310,19 @@ __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const Co
     store_chunk(pf0);
     if constexpr (NCH == 2) load_chunk(cur, 1, pf1);
     if constexpr (!PF0S1) load_chunk(nxt, 0, pf0);
-    if constexpr (HAS_R1 && !(RES_IN_S1 && NCH == 2)) load_res(cur, tile_of(0) < ntiles);
+    if constexpr (HAS_R1 && !(RES_IN_S1 && NCH == 2)) load_res(cur, tile_of(0) < ntiles, 0, (PP_RES_SPLIT && NCH == 2) ? 1 : MTW);
     lds_barrier();                       // weights, bias and both groups' first patches are in place
     if (g) lds_barrier();                // group 1 runs one phase behind group 0
 
+#ifdef DSVC_PP_PROBE
+    unsigned long long ppw[4] = {0, 0, 0, 0}, ppb[4] = {0, 0, 0, 0}, t_last;
+    PP_STAMP(t_last)
+#endif
     for (int k = 0; k < iters; ++k) {
         const bool valid = tile_of(k) < ntiles;
         // ---- M0 ----
         mfma_phase(0, true);
-        lds_barrier();
+        PP_BARRIER(0)
         if constexpr (NCH == 2) {
             // ---- S1 (+ prefetch: next tile's chunk 1) ----
             store_chunk(pf1);
@@ -308,10 +332,11 @@ __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const Co
             // phase while this one is the shortest; the data is consumed at the end of this iteration's E phase (M1 + E later)
             if constexpr (PF0S1) load_chunk(nxt, 0, pf0);
             if constexpr (HAS_R1 && RES_IN_S1) load_res(cur, valid);
-            lds_barrier();
+            if constexpr (HAS_R1 && PP_RES_SPLIT && NCH == 2) load_res(cur, valid, 1, 2);
+            PP_BARRIER(1)
             // ---- M1 ----
             mfma_phase(1, false);
-            lds_barrier();
+            PP_BARRIER(2)
         }
         // ---- E + S0 (+ prefetch: chunk 0 of the tile after next, the next tile's residual) ----
         if constexpr (HEAD) {
@@ -436,9 +461,16 @@ __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const Co
         cur = nxt;
         nxt = tile_origin(min(tile_of(k + 2), ntiles - 1));
         if constexpr (!PF0S1) load_chunk(nxt, 0, pf0);
-        if constexpr (HAS_R1 && !(RES_IN_S1 && NCH == 2)) load_res(cur, tile_of(k + 1) < ntiles);
-        lds_barrier();
+        if constexpr (HAS_R1 && !(RES_IN_S1 && NCH == 2)) load_res(cur, tile_of(k + 1) < ntiles, 0, (PP_RES_SPLIT && NCH == 2) ? 1 : MTW);
+        PP_BARRIER(3)
     }
+#ifdef DSVC_PP_PROBE
+    if (wg == 0 && lane == 0) {
+        for (int i = 0; i < 4; ++i) { atomicAdd(&g_pp_phase[g * 8 + 2 * i], ppw[i]); atomicAdd(&g_pp_phase[g * 8 + 2 * i + 1], ppb[i]); }
+        if (g == 0) atomicAdd(&g_pp_phase[16], (unsigned long long)iters);
+    }
+#endif
+
     if (!g) lds_barrier();               // matches group 1's leading barrier
 }
 
