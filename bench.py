@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-side-legs", action="store_true", help="headline leg only (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--switch-interval", type=float, default=float(os.environ.get("DSVC_SWITCH_INTERVAL", "0.005")),
+                    help="sys.setswitchinterval for the lane / coder threads (seconds)")
     return ap.parse_args()
 
 
@@ -133,6 +135,7 @@ def main():
     if env_world is None and args.gpus > 1:
         return launch_ranks(args)
     import torch
+    sys.setswitchinterval(args.switch_interval)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(env_world or "1")

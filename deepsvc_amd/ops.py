@@ -50,7 +50,17 @@ def get_precision():
     return RT.mode
 
 
+_SLOW_STREAM = __import__("os").environ.get("DSVC_SLOW_STREAM", "") != ""      # A/B switch (tools/host_overhead.py)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The calling thread's current HIP stream as a void*.  `torch.cuda.current_stream()` costs ~10 us of Python per call (device
+    index plumbing), i.e. ~4 ms per frame over ~380 launches -- a third of a lane thread's host time (tools/host_overhead.py);
+    the raw accessor torch itself uses is a plain C call."""
+    if _raw_stream is not None and _cur_device is not None and not _SLOW_STREAM:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
