@@ -42,15 +42,16 @@ class Conv2d(nn.Conv2d):
     """nn.Conv2d parameters (same keys) executed by the fused MFMA conv kernel."""
 
     def _packed(self, seg_channels, device, phys_channels=None, s2d=False):
-        key = (tuple(seg_channels), None if phys_channels is None else tuple(phys_channels), ops.RT.compute, str(device),
-               self.weight._version, -1 if self.bias is None else self.bias._version, self.weight.data_ptr(), s2d)
-        cache = self.__dict__.setdefault("_pack_cache", {})
-        if key not in cache:
-            cache.clear()
-            cache[key] = ops.PackedConv(self.weight, self.bias, seg_channels, self.stride[0], self.padding[0],
-                                        ops.RT.compute, device, phys_channels, s2d=s2d)
-            _bump_owner_epoch(self)
-        return cache[key]
+        w, b = self.weight, self.bias
+        key = (tuple(seg_channels), None if phys_channels is None else tuple(phys_channels), ops.RT.compute, device,
+               w._version, -1 if b is None else b._version, w.data_ptr(), s2d)
+        last = self.__dict__.get("_pack_last")            # (key, PackedConv): one entry -- a layer is used with one configuration
+        if last is not None and last[0] == key:
+            return last[1]
+        pc = ops.PackedConv(w, b, seg_channels, self.stride[0], self.padding[0], ops.RT.compute, device, phys_channels, s2d=s2d)
+        self.__dict__["_pack_last"] = (key, pc)
+        _bump_owner_epoch(self)
+        return pc
 
     def _s2d_ok(self, phys_inputs):
         """f16 mode: conv5x5/s2 runs as a 3x3/s1 conv over the space-to-depth view of its inputs (include/dsvc.h: s2d) when

@@ -24,4 +24,4 @@ for size in (64, 256):
     print(f"{size}x{size}: {dt * 1e3:.2f} ms per frame (host-bound)")
     if size == 64:
         pr = cProfile.Profile(); pr.enable(); gop(2); pr.disable()
-        st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(18)
+        st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
