@@ -118,3 +118,21 @@ def test_reference_harness_call_sequence_through_dropin(tmp_path, oracle_w0):
         e_r, e_f = PU.rel_l2(dec_g.cpu(), ref_o), PU.rel_l2(feat_g.cpu(), feat_o)
         print(f"[dropin] frame {i}: recon rel-L2 {e_r:.2e}, feature rel-L2 {e_f:.2e}, bpp {rows[i][1]:.3f}, PSNR {rows[i][2]:.2f} dB")
         assert e_r <= PU.FP32_BOUNDS["recon"] and e_f <= PU.FP32_BOUNDS["feature"]
+
+
+def test_bench_launches_its_own_ranks_on_the_gpu_box():
+    """`python bench.py --gpus 2` (no launcher around it) must start two ranks itself and report them: on the one-GPU test box the
+    ranks share cuda:0 and talk over gloo (DSVC_BENCH_REHEARSAL=1; on a multi-GPU node the same code path uses one GPU per rank and
+    RCCL).  Small frames, two steps: this checks the plumbing -- process group, barriers, max-over-ranks timing, the metrics gather,
+    one JSON line on stdout -- not throughput."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["DSVC_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "256x256", "--steps", "2", "--warmup", "1",
+                        "--lanes", "2", "--no-cpu-baseline", "--no-side-legs"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly the JSON line, got {len(lines)} lines"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["frames_per_step"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
