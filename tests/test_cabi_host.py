@@ -189,3 +189,28 @@ def test_malformed_cdf_tables_are_rejected():
             ops.CdfTables(bad, lens, offs)
     with pytest.raises(RuntimeError):
         ops.CdfTables(good, np.array([4, 6], dtype=np.int32), offs)        # cdf_length beyond the row stride
+
+
+def test_scan_op_ctypes_mirrors_match_the_header(tmp_path):
+    """dsvc_scan_op and its union members (dsvc_entropy_scan_step's op list) must lay out exactly like the C structs: sizes and
+    field offsets from gcc against the ctypes mirrors in deepsvc_amd/_native.py."""
+    import ctypes
+    import subprocess
+    structs = {"dsvc_scan_gc": N.ScanGc, "dsvc_scan_eb": N.ScanEb, "dsvc_scan_ew": N.ScanEw, "dsvc_scan_op": N.ScanOp}
+    lines = []
+    for cname, cls in structs.items():
+        for f, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+    src = tmp_path / "scan_layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dsvc.h"\nint main(void){\n' + "\n".join(lines) + "\nreturn 0;}\n")
+    exe = tmp_path / "scan_layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.rsplit(" ", 1) for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in structs.items():
+        assert ctypes.sizeof(cls) == int(got[cname]), f"sizeof({cname}): ctypes {ctypes.sizeof(cls)} != C {got[cname]}"
+        for f, _ in cls._fields_:
+            assert getattr(cls, f).offset == int(got[f"{cname}.{f}"]), f"{cname}.{f}: ctypes offset {getattr(cls, f).offset} != C {got[cname + '.' + f]}"
+    # the union's members all start at the union's offset
+    assert N._ScanU.conv.offset == N._ScanU.gc.offset == N._ScanU.eb.offset == N._ScanU.ew.offset == 0
+    assert ctypes.sizeof(N._ScanU) == max(ctypes.sizeof(c) for c in (N.ConvDesc, N.ScanGc, N.ScanEb, N.ScanEw))
