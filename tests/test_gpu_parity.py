@@ -244,3 +244,35 @@ def test_f16_mode_vs_fp32_oracle(oracle_w0):
             ref_g, feat_g, ref_o, feat_o = dec_g[1], dec_g[0], dec_o[1], dec_o[0]
     finally:
         ops.set_precision("fp32")
+
+
+def test_batch_of_two(model, oracle_w0):
+    """B = 2 through the same API (the reference's compress writes ONE y-string for the whole batch and one z-string per item,
+    image_model.py:253-255 / SURVEY section 9.12; its decompress reshapes to batch 1, :289, so batch decoding is a superset here):
+    the estimate path and a codec's batch bitstream against the oracle, and the batched P-frame decode bit-identical to decoding
+    each item on its own."""
+    from deepsvc_amd import ops, synth
+    ops.set_precision("fp32")
+    size = 64
+    a, b = synth.make_frames(size, size, 2, seed=1234), synth.make_frames(size, size, 2, seed=99)
+    ref, cur = torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])
+    sm = torch.cat([synth.make_sm_fea(size, size, 1, seed=1234), synth.make_sm_fea(size, size, 1, seed=99)])
+    fw, fo = model(ref.to(DEV), cur.to(DEV), sm.to(DEV), None), oracle_w0.forward(ref, cur, sm, None)
+    assert PU.rel_l2(fw[0].cpu(), fo[0]) <= 1e-5 and PU.rel_l2(fw[1].float().cpu(), fo[1]) <= 1e-5
+    assert abs(float(fw[7]) - float(fo[7])) <= 1e-3 * float(fo[7])
+    # codec level: the reference's compress handles a batch (one y-string, one z-string per item) -- bytes vs the oracle.  (Its
+    # DeepSVC.compress decodes its own mv stream with the batch-1 decompress, so the reference itself stops there for B > 1.)
+    from oracle import codec as OC
+    torch.manual_seed(5)
+    x8 = torch.randn(2, 8, size, size) * 0.5
+    enc_g = model.mv_codec.compress(x8.to(DEV))
+    enc_o = OC.codec_compress(oracle_w0.root.sub("mv_codec"), oracle_w0.tables["mv"], x8)
+    assert len(enc_g["strings"][0]) == 1 and len(enc_g["strings"][1]) == 2
+    assert enc_g["strings"][0][0] == enc_o["strings"][0][0] and list(enc_g["strings"][1]) == list(enc_o["strings"][1]), "batch bitstream differs from the oracle's"
+    mv, res = model.compress(ref.to(DEV), cur.to(DEV), sm.to(DEV), None)
+    dec = model.decompress(ref.to(DEV), mv, res, sm.to(DEV), None)
+    assert tuple(dec[1].shape) == (2, 3, size, size) and tuple(dec[0].shape) == (2, 64, size, size)
+    for i, fr in enumerate((a, b)):
+        mv1, res1 = model.compress(fr[0].to(DEV), fr[1].to(DEV), sm[i:i + 1].to(DEV), None)
+        d1 = model.decompress(fr[0].to(DEV), mv1, res1, sm[i:i + 1].to(DEV), None)
+        assert torch.equal(dec[1][i:i + 1], d1[1]) and torch.equal(dec[0][i:i + 1].float(), d1[0].float()), f"item {i}: batched decode differs"
