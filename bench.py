@@ -41,7 +41,9 @@ HBM_PEAK = 8.0e12                                    # B/s
 FLOP_PER_PX = {2: 8.571e6,      # GOP = 7: mean over the 6 P-frames (first P 8.453e6, steady-state 8.594e6)
                3: 8.076e6}      # GOP = 12 with the intra-coded key frame: mean over all 12 frames
 GOP_OF = {2: 7, 3: 12}
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc.json")
+if not os.path.exists(PMC_FILE):
+    PMC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")
 
 
 def parse():
@@ -57,6 +59,7 @@ def parse():
     ap.add_argument("--no-side-legs", action="store_true", help="headline leg only (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--no-cpu-full-frame", action="store_true", help="skip the one full-size oracle P-frame of the cpu_baseline leg (~15-40 s of CPU)")
     ap.add_argument("--switch-interval", type=float, default=float(os.environ.get("DSVC_SWITCH_INTERVAL", "0.005")),
                     help="sys.setswitchinterval for the lane / coder threads (seconds)")
     return ap.parse_args()
@@ -95,35 +98,40 @@ def launch_ranks(args):
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1): the oracle on the host cores
 # ------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(sample, n_frames, threads, H_pad, W_pad):
+def cpu_baseline(sample_hw, n_frames, threads, H_pad, W_pad):
     """The oracle (CPU restatement of the reference path, oracle/) timed on this host: `n_frames` chained P-frames
-    (compress + decompress each; state chaining of test_video.py:342-369) at sample x sample with `threads` torch threads
-    (1 = the reference harness's own setting, test_video.py:16); scaled to the padded frame by the pixel ratio (the cost is
-    per-pixel: SURVEY section 8d).  Baseline only -- never the measured path."""
+    (compress + decompress each; state chaining of test_video.py:342-369) at sample_hw = (h, w) with `threads` torch threads
+    (1 = the reference harness's own setting, test_video.py:16); scaled to the padded frame by the pixel ratio when the sample
+    is smaller (the cost is per-pixel: SURVEY section 8d).  Baseline only -- never the measured path."""
     import torch
     from deepsvc_amd import synth
     from oracle.codec import DeepSVCOracle
+    sh, sw = sample_hw
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
         orc = DeepSVCOracle(synth.make_model("W0").state_dict())
         orc.update()
-        fr = synth.make_frames(sample, sample, n_frames + 1)
-        ref, feat, per = fr[0], None, []
+        fr = synth.make_frames(sh, sw, n_frames + 1)
+        ref, feat, per, split = fr[0], None, [], []
         for t in range(1, n_frames + 1):
-            sm = synth.make_sm_fea(sample, sample, t)
+            sm = synth.make_sm_fea(sh, sw, t)
             t0 = time.perf_counter()
             mv, res = orc.compress(ref, fr[t], sm, feat)
+            t1 = time.perf_counter()
             feat, ref, _, _ = orc.decompress(ref, mv, res, sm, feat)
             per.append(time.perf_counter() - t0)
+            split.append((t1 - t0, per[-1] - (t1 - t0)))
     finally:
         torch.set_num_threads(prev)
     t_tot = sum(per)
-    scale = (sample * sample) / float(H_pad * W_pad)
+    scale = (sh * sw) / float(H_pad * W_pad)
+    what = "scaled by pixel ratio to" if scale != 1.0 else "the full padded frame"
     return {"value": n_frames / t_tot * scale, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n_frames} chained P-frames (compress+decompress) at {sample}x{sample}, {t_tot:.1f} s of CPU "
-                      f"(per frame min {min(per):.2f} / max {max(per):.2f} s), scaled by pixel ratio to {H_pad}x{W_pad}; "
-                      f"oracle = PyTorch-CPU restatement of the reference, pinned byte for byte by the reference's golden vectors"}
+            "sample": f"{n_frames} chained P-frame(s) (compress+decompress) at {sh}x{sw}, {t_tot:.1f} s of CPU "
+                      f"(per frame min {min(per):.2f} / max {max(per):.2f} s; encode {sum(a for a, _ in split):.1f} s, decode {sum(b for _, b in split):.1f} s), "
+                      f"{what} {H_pad}x{W_pad}; oracle = PyTorch-CPU restatement of the reference, pinned byte for byte by the reference's "
+                      f"golden vectors (incl. {H_pad}x{W_pad} when that is 1088x1920)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -142,7 +150,10 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     ranks_seen = 1
-    if world > 1:
+    # DSVC_BENCH_FORCE_PG=1: build the process group even for ONE rank, so that init_process_group(nccl, device_id), barrier,
+    # all_reduce(MAX) and the all_gather of the metric rows execute on RCCL on a 1-GPU box (tests/test_gpu_dropin.py)
+    use_pg = world > 1 or bool(os.environ.get("DSVC_BENCH_FORCE_PG"))
+    if use_pg:
         import torch.distributed as dist
         if os.environ.get("DSVC_BENCH_REHEARSAL"):      # N ranks sharing the ONE GPU of a development box: gloo, all on cuda:0
             dist.init_process_group(backend="gloo")        # (exercises the rank / barrier / gather plumbing, not RCCL)
@@ -154,7 +165,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:           # N ranks share the host: keep each rank's torch CPU thread pool to its share of the cores
-        torch.set_num_threads(max(1, (os.cpu_count() or 16) // world))
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 16)
+        torch.set_num_threads(max(1, cores // world))
 
     from deepsvc_amd import harness, ops, synth
     from deepsvc_amd.modules import pad
@@ -165,14 +177,14 @@ def main():
     conv_flop = 2.0 * H_pad * W_pad * 64 * 64 * 9
 
     def barrier():
-        if world > 1:
+        if use_pg:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
         t = torch.tensor([x], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_pg:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t)
@@ -248,11 +260,9 @@ def main():
 
     full_res = lambda pc, x0: (pc.kh == 3 and pc.stride == 1 and pc.segC == (64,) and pc.Cout == 64 and x0.H == H_pad and x0.W == W_pad)
 
-    nres = [0.0]          # mean number of residual operands per dominant launch of the last timed region
-
     def timed(lanes, n):
         """Barrier + synchronize on both sides; every launch of the dominant conv shape inside is bracketed by HIP events on
-        its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank])"""
+        its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank], {residual operands: launches})"""
         ops.PROFILE = {"match": full_res, "pairs": []}
         barrier()
         t0 = time.perf_counter()
@@ -268,13 +278,35 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         prof, ops.PROFILE = ops.PROFILE, None
-        nres[0] = (sum(prof.get("nres", [])) / max(len(prof.get("nres", [])), 1))
-        return max_over_ranks(elapsed), [a.elapsed_time(b) for a, b in prof["pairs"]]
+        hist = {k: prof.get("nres", []).count(k) for k in (0, 1, 2)}
+        return max_over_ranks(elapsed), [a.elapsed_time(b) for a, b in prof["pairs"]], hist
 
-    def roofline_of(durs, precision, extra=None):
+    def pmc_traffic(section, hist):
+        """HBM bytes per launch from the committed rocprofv3 --pmc passes (they cannot run in-process), weighted by THIS region's
+        launch mix: the PMC file holds bytes per launch for launches with 0 / 1 / 2 residual operands."""
+        if not os.path.exists(PMC_FILE):
+            return None, {}
+        with open(PMC_FILE) as f:
+            pmc = json.load(f)
+        sec = pmc.get(section) or (pmc if section == "f16" and "variants" in pmc else None)
+        if not sec:
+            return None, {}
+        by = sec.get("by_residual_operands")
+        n = sum(hist.values())
+        if by and n and all(str(k) in by for k, c in hist.items() if c):
+            tr = sum(by[str(k)]["hbm_bytes_per_launch_corrected"] * c for k, c in hist.items() if c) / n
+            al = sum(by[str(k)]["algorithmic_bytes_per_launch"] * c for k, c in hist.items() if c) / n
+        else:
+            tr, al = sec.get("hbm_bytes_per_launch_corrected"), sec.get("algorithmic_bytes_per_launch")
+        return tr, {"traffic_over_algorithmic": tr / al if tr and al else None, "traffic_algorithmic_bytes": al,
+                    "traffic_source": f"{os.path.relpath(PMC_FILE, ROOT)} [{section}]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --lanes 1` "
+                                      "(FETCH_SIZE x2 per MI355X_MICROARCH.md), bytes per launch by number of residual operands, weighted by this region's launch mix"}
+
+    def roofline_of(durs, precision, hist, extra=None):
         if not durs:
             return None
         avg_ms = sum(durs) / len(durs)
+        nres = [sum(k * c for k, c in hist.items()) / max(sum(hist.values()), 1)]
         achieved = conv_flop / (avg_ms * 1e-3) / 1e12
         esz = 2 if precision == "f16" else 4
         alg_bytes = (2.0 + nres[0]) * H_pad * W_pad * 64 * esz       # input + output + the residual operand(s), launch-weighted mean
@@ -287,25 +319,28 @@ def main():
                           "note": "algorithmic bytes = input + output + residual operand(s), launch-weighted over the epilogue variants; the kernel is "
                                   "not HBM-bound: a producer->consumer chain runs at the same 0.9 PFLOP/s on Infinity-Cache-resident 67 MB tensors "
                                   "(tools/bench_chain.py, DESIGN.md section 4.2)"}}
+        if (h, w) == (1080, 1920) and rank == 0:
+            r["traffic"], more = pmc_traffic(precision, hist)
+            r.update(more)
         r.update(extra or {})
         return r
 
     # ---- headline leg ------------------------------------------------------------------------------------------------
     lanes = [make_lane(ln, args.precision) for ln in range(args.lanes)]
     warm(lanes, args.warmup)
-    t_max, durs_shared = timed(lanes, args.steps)
+    t_max, durs_shared, hist_shared = timed(lanes, args.steps)
     rows = [r for L in lanes for r in L["rows"]]
     hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30
 
     side = not args.no_side_legs
     lanes1 = parity = deltas = None
-    durs_own = durs_shared if (args.lanes == 1 or not side) else None     # without the lanes1 leg only the time-shared durations exist
+    durs_own, hist_own = (durs_shared, hist_shared) if (args.lanes == 1 or not side) else (None, {})     # without the lanes1 leg only the time-shared durations exist
     if side and args.lanes > 1:
         # ---- the same mode, ONE GOP in flight: the kernel's own durations ----
         for L in lanes:
             L["rows"] = []
         n1 = GOP if intra else GOP - 1
-        t1, durs_own = timed(lanes[:1], n1)
+        t1, durs_own, hist_own = timed(lanes[:1], n1)
         lanes1 = {"value": n1 * world / t1, "unit": "frames/s", "steps": n1, "ms_per_step": 1000.0 * t1 / n1, "gop_lanes": 1}
     if side and args.precision == "f16" and not intra:
         # ---- reference precision: fp32 mode, one GOP in flight ----
@@ -314,9 +349,9 @@ def main():
             f32 = make_lane(0, "fp32")
             warm([f32], 2)
             n32 = GOP - 1
-            t32, durs32 = timed([f32], n32)
+            t32, durs32, hist32 = timed([f32], n32)
             parity = {"dtype": "f32", "value": n32 * world / t32, "unit": "frames/s", "steps": n32, "ms_per_step": 1000.0 * t32 / n32,
-                      "gop_lanes": 1, "roofline": roofline_of(durs32, "fp32"),
+                      "gop_lanes": 1, "roofline": roofline_of(durs32, "fp32", hist32),
                       "whole_frame_tflops": n32 / t32 * FLOP_PER_PX[2] * H_pad * W_pad / 1e12,
                       "note": "fp32 storage + v_mfma_f32_32x32x2_f32: the reference's arithmetic (PyTorch fp32); bitstreams byte-identical "
                               "to the reference's golden strings at 64/128/256 px (tests/test_gpu_parity.py)"}
@@ -351,6 +386,32 @@ def main():
                           "recon_rel_l2": worst("recon_rel_l2"),
                           "note": "worst |delta| over 3 chained P-frames of lane 0's GOP, each mode chained on its own decoded state; "
                                   "un-clamped reconstruction and decoded 64-channel feature; north_star tolerance: 1 % bpp, 0.05 dB"}
+                # ---- both modes against the REFERENCE's own run at this size (tests/golden/deepsvc_ref_1080p.npz: the reference's
+                #      compress()/decompress() on synth.make_frames(1088, 1920, 3), made in the build container) ----
+                gpath = os.path.join(ROOT, "tests", "golden", "deepsvc_ref_1080p.npz")
+                if (H_pad, W_pad) == (1088, 1920) and os.path.exists(gpath):
+                    import numpy as np
+                    g = np.load(gpath)
+                    gfr = [f.to(dev) for f in synth.make_frames(1088, 1920, 3)]
+                    vs = {}
+                    for mode, L in (("fp32", f32), ("f16", h16)):
+                        ops.set_precision(mode)
+                        ref, feat, fr_rows = gfr[0], None, []
+                        for t in (1, 2):
+                            sm = synth.make_sm_fea(1088, 1920, t).to(dev)
+                            mv, res = L["model"].compress(ref, gfr[t], sm, feat)
+                            feat, recon, _, _ = L["model"].decompress(ref, mv, res, sm, feat)
+                            gold = [g[f"s1080/f{t}/enc/{c}_{k}"].tobytes() for c in ("mv", "res") for k in ("y", "z")]
+                            mine = [e["strings"][i][0] for e in (mv, res) for i in (0, 1)]
+                            nb, ng = sum(len(x) for x in mine), sum(len(x) for x in gold)
+                            e_s, e_b, _ = PU.golden_full_errors(g, f"s1080/f{t}/dec/recon", recon)
+                            fr_rows.append({"frame": t, "bytes": nb, "bytes_reference": ng, "bytes_identical": mine == gold, "dbpp_pct": 100.0 * (nb - ng) / ng,
+                                            "dpsnr_db": PU.psnr(recon, gfr[t]) - float(g["s1080/psnr"][t - 1]),
+                                            "recon_rel_l2_samples": e_s, "recon_rel_l2_block_means": e_b})
+                            ref = recon
+                        vs[mode] = fr_rows
+                    deltas["vs_reference_golden"] = dict(vs, note="first + steady-state P-frame of the reference's own 1088x1920 run (clamped decoded frames, "
+                                                                  "strided samples and block means); asserted in tests/test_gpu_fullsize.py")
         finally:
             ops.set_precision(args.precision)
 
@@ -364,16 +425,8 @@ def main():
     if rank == 0:
         total_frames = args.steps * world * args.lanes
         fps = total_frames / t_max
-        traffic = None
-        extra = {}
-        if args.precision == "f16" and (h, w) == (1080, 1920) and os.path.exists(PMC_FILE):
-            with open(PMC_FILE) as f:       # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (cannot run in-process)
-                pmc = json.load(f)
-            traffic = pmc.get("hbm_bytes_per_launch_corrected")
-            extra["traffic_source"] = "profiles/r02_dominant_kernel_pmc.json (separate rocprofv3 --pmc passes of `bench.py --lanes 1`, per launch, corrected per MI355X_MICROARCH.md)"
-        roof = roofline_of(durs_own, args.precision, extra)
+        roof = roofline_of(durs_own, args.precision, hist_own)
         if roof is not None:
-            roof["traffic"] = traffic
             roof["measured_in"] = "lanes1 leg (one GOP in flight): HIP events on the launch stream around every launch of this shape" if args.lanes > 1 and side \
                 else ("timed region (one GOP in flight): HIP events on the launch stream around every launch of this shape" if args.lanes == 1 else
                       f"timed region with {args.lanes} lanes in flight (--no-side-legs): durations are TIME-SHARED with the other lanes' kernels, not the kernel's own cost")
@@ -394,7 +447,13 @@ def main():
                                      f"GOP lane(s) in flight per GPU (one step = one frame on every lane)",
                        "precision": args.precision, "gop_lanes": args.lanes, "frames_per_step": args.lanes * world,
                        "hbm_peak_gb": hbm_peak_gb, "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
-                       "whole_frame_tflops": fps * FLOP_PER_PX[args.config] * H_pad * W_pad / 1e12 / world},
+                       "whole_frame_tflops": fps * FLOP_PER_PX[args.config] * H_pad * W_pad / 1e12 / world,
+                       # the other legs of this run as scalars (details in the objects of the same names below)
+                       "lanes1_fps": None if lanes1 is None else lanes1["value"],
+                       "lanes1_ms_per_frame": None if lanes1 is None else lanes1["ms_per_step"],
+                       "parity_mode_fp32_fps": None if parity is None else parity["value"],
+                       "parity_mode_fp32_roofline_frac": None if parity is None or parity["roofline"] is None else parity["roofline"]["frac"],
+                       "f16_roofline_frac": None if roof is None else roof["frac"]},
             "roofline": roof,
         }
         if lanes1 is not None:
@@ -407,10 +466,16 @@ def main():
             import torch as _t
             # all-core leg: this process's CPU share on a 1-GPU box is 16 cores; more threads than that on a 256x256 image only
             # add synchronisation cost (128 threads measured slower than 1)
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_frames, min(_t.get_num_threads(), 16), H_pad, W_pad)
-            line["cpu_baseline_1thread"] = cpu_baseline(args.cpu_sample, args.cpu_frames, 1, H_pad, W_pad)
+            cores = min(_t.get_num_threads(), 16)
+            small = cpu_baseline((args.cpu_sample, args.cpu_sample), args.cpu_frames, cores, H_pad, W_pad)
+            if args.no_cpu_full_frame:
+                line["cpu_baseline"] = small
+            else:         # one measured P-frame at the benchmark's own size, all cores of this process's share
+                line["cpu_baseline"] = cpu_baseline((H_pad, W_pad), 1, cores, H_pad, W_pad)
+                line["cpu_baseline_small_sample"] = small
+            line["cpu_baseline_1thread"] = cpu_baseline((args.cpu_sample, args.cpu_sample), args.cpu_frames, 1, H_pad, W_pad)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -10,6 +10,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSVC_LIB") or os.path.join(HERE, "lib", "libdsvc.so")     # DSVC_LIB: an instrumented build (tools/phase_probe.py)
 
+ABI_VERSION = 2            # include/dsvc.h: DSVC_VERSION this binding was written against
 F32, F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_HALF_TANH = range(6)
 EW_COPY, EW_ADD, EW_SUB, EW_BLEND2, EW_BLEND3, EW_CLAMP01 = range(6)
@@ -93,6 +94,7 @@ SIGNATURES = {
     "dsvc_version": (c_int, []),
     "dsvc_device_count": (c_int, []),
     "dsvc_set_option": (c_int, [c_char_p, c_int]),
+    "dsvc_get_counter": (c_int64, [c_char_p]),
     "dsvc_conv_packed_bytes": (c_int64, [c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32]),
     "dsvc_conv_pack_weights": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "dsvc_deconv5x5s2_to_conv3x3": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
@@ -155,6 +157,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        if L.dsvc_version() != ABI_VERSION:      # a stale build would silently reinterpret dtype codes / struct layouts
+            raise NativeError(f"{LIB_PATH} reports ABI version {L.dsvc_version()}, this binding needs {ABI_VERSION}: "
+                              "rebuild it with `python -m deepsvc_amd.build --force`")
         _lib = L
     return _lib
 

@@ -37,12 +37,24 @@ struct DsvcOptions {
 };
 extern DsvcOptions g_dsvc_opt;
 
+// ---- launch counters (dsvc_get_counter, host_misc.cpp): which conv kernel family took a launch ----------------
+enum { DSVC_CNT_GENERIC = 0, DSVC_CNT_PP, DSVC_CNT_WS, DSVC_CNT_CONV1X1, DSVC_CNT_PP_POST, DSVC_CNT_N };
+extern long long g_dsvc_counters[DSVC_CNT_N];
+static inline void dsvc_count(int which) { __atomic_fetch_add(&g_dsvc_counters[which], 1, __ATOMIC_RELAXED); }
+
+// ---- f16 stores saturate ----------------------------------------------------------------------
+// MODE.FP16_OVFL (hwreg MODE bit 23): an overflowed f16 conversion result is clamped to +-65504 instead of becoming +-inf
+// (true infinities and NaNs pass through).  Every kernel that can store binary16 sets it first: a trained checkpoint whose
+// activations exceed the f16 range then degrades gracefully -- encoder and decoder saturate identically, so streams stay
+// decodable -- instead of poisoning the latents with inf / NaN (tests/test_gpu_ops.py::test_f16_stores_saturate).
+#define DSVC_F16_SAT() __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1)
+
 // ---- element access with runtime storage type ------------------------------------------------
 __device__ __forceinline__ float h16_bits_to_f32(unsigned short b) {
     return (float)__builtin_bit_cast(h16, b);
 }
 __device__ __forceinline__ unsigned short f32_to_h16_bits(float f) {
-    return __builtin_bit_cast(unsigned short, (h16)f);  // v_cvt_f16_f32: RNE, overflow -> inf, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, (h16)f);  // v_cvt_f16_f32: RNE; overflow saturates under DSVC_F16_SAT(), NaN stays NaN
 }
 // the two halves of a packed dword as floats / two floats -> one packed dword (low half = a; one v_cvt_pk_f16_f32, RNE)
 __device__ __forceinline__ float h16_lo(unsigned u) { return (float)__builtin_bit_cast(h16x2, u).x; }

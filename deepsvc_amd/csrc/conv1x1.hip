@@ -29,6 +29,7 @@ namespace {
 // HAS_GATE: out = act(conv) + gate[c] * res1 (the SE gate of modules.py:226-247, batch 1).
 template <int KS, int NT, bool HAS_R1, bool HAS_GATE>
 __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p, int nunits, float act_slope) {
+    DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NCH = (KS + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
 
 template <int KS, int NT>
 __global__ void __launch_bounds__(256) conv1x1_kernel(const ConvParams p, int nunits) {
+    DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPN = NT >= 2 ? 2 : 1;
     constexpr int EPLD = EPN * 32 + 4, GPP = EPN * 8;

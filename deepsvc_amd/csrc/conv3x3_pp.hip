@@ -113,6 +113,7 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
 template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false>
 __global__ void __launch_bounds__(512, PP_MIN_BLOCKS) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
                                                               float pre_slope) {
+    DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTN = NT * 32, MTW = 2;
     // where the next tile's chunk-0 loads are issued: in the S1 phase (the shortest one) instead of the E phase (the longest: 8 stores

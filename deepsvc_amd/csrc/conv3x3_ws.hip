@@ -28,6 +28,7 @@ constexpr int WS_TH = 16, WS_PH = 18, WS_PW = 34, WS_NPATCH = WS_PH * WS_PW;   /
 // (every fragment read feeds twice the MFMAs, no MFMA-pipe contention between lock-stepped partner waves).
 template <int NT, bool FAST, bool DIRECT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) conv3x3_ws_kernel(const ConvParams p, int ntiles) {
+    DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTN = NT * 32, KCE = 32, EPV = 8;
     constexpr int NTHR = WAVES * 64, MTW = 16 / WAVES;          // tile rows per wave

@@ -62,6 +62,7 @@ using namespace dsvc_conv;
 // into PF registers per thread during the last MFMA phase of the current chunk, like the weights.
 template <typename CT, int MT, int NT, bool FAST, bool REGEPI = false, int PF = 0>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
+    DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KCE = CTraits<CT>::KCE, EPV = CTraits<CT>::EPV;
     constexpr int TH = 4 * MT, NTN = NT * 32;
@@ -709,18 +710,22 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     if (p.post_w) {                          // fused trailing 1x1 conv: only the two-group 3x3 kernel implements it
         const int rc = dsvc_conv3x3_pp_try((hipStream_t)stream, p, d);
         DSVC_REQUIRE(rc != 1, "conv2d: post_weight (fused 1x1) is not supported for this shape / type combination");
+        if (rc == DSVC_OK) { dsvc_count(DSVC_CNT_PP); dsvc_count(DSVC_CNT_PP_POST); }
         return rc;
     }
     if (opt.specialised && opt.conv1x1) {   // f16 pointwise convs: streaming kernel, no LDS staging
         const int rc = dsvc_conv1x1_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_CONV1X1);
         if (rc != 1) return rc;
     }
     if (opt.specialised && opt.pp) {        // 64-channel f16 ResBlock family: two phase-skewed wave groups per CU
         const int rc = dsvc_conv3x3_pp_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_PP);
         if (rc != 1) return rc;
     }
     if (opt.specialised && opt.ws) {        // other large f16 3x3 convs with <= 64 input channels: LDS-resident weights
         const int rc = dsvc_conv3x3_ws_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_WS);
         if (rc != 1) return rc;
     }
     // ---- tile configuration ----
@@ -784,6 +789,7 @@ extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
     DSVC_REQUIRE(lds <= 160 * 1024, "conv2d: LDS need %zu exceeds 160 KiB", lds);
 
     hipStream_t st = (hipStream_t)stream;
+    dsvc_count(DSVC_CNT_GENERIC);
     if (d->compute == DSVC_F32) return launch_ct<float>(st, p, MT, NT, fast, ngroups, lds);
     return launch_ct<h16>(st, p, MT, NT, fast, ngroups, lds);
 }

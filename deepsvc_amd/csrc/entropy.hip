@@ -22,6 +22,7 @@ __device__ __forceinline__ float phi_c(float x) { return 0.5f * erfcf(-0.7071067
 __global__ void gc_quantize_kernel(const void* y, int y_ld, const void* mu, int mu_ld, const void* sc, int sc_ld, int dt,
                                    const float* table, int levels, int B, int H, int W, int C,
                                    int32_t* sym, int32_t* idx, void* yhat, int yhat_ld) {
+    DSVC_F16_SAT();
     const int64_t HW = (int64_t)H * W, total = (int64_t)B * C * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i % HW;
@@ -45,6 +46,7 @@ __global__ void gc_quantize_kernel(const void* y, int y_ld, const void* mu, int 
 
 __global__ void gc_dequantize_kernel(const int32_t* sym, const void* mu, int mu_ld, int dt, int B, int H, int W, int C,
                                      void* yhat, int yhat_ld) {
+    DSVC_F16_SAT();
     const int64_t HW = (int64_t)H * W, total = (int64_t)B * C * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i % HW;
@@ -57,6 +59,7 @@ __global__ void gc_dequantize_kernel(const int32_t* sym, const void* mu, int mu_
 
 __global__ void gc_likelihood_kernel(const void* y, int y_ld, const void* mu, int mu_ld, const void* sc, int sc_ld, int dt,
                                      int64_t n_pix, int C, void* yhat, int yhat_ld, float* lik, int lik_ld) {
+    DSVC_F16_SAT();
     const int64_t total = n_pix * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -98,6 +101,7 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x
 
 __global__ void eb_process_kernel(const void* z, int z_ld, int dt, const float* params, int B, int H, int W, int C, int mode,
                                   int32_t* sym, void* zhat, int zhat_ld, float* lik, int lik_ld) {
+    DSVC_F16_SAT();
     const int64_t HW = (int64_t)H * W, total = (int64_t)B * C * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i % HW;
@@ -120,6 +124,7 @@ __global__ void eb_process_kernel(const void* z, int z_ld, int dt, const float* 
 }
 
 __global__ void eb_dequantize_kernel(const int32_t* sym, const float* params, int dt, int B, int H, int W, int C, void* zhat, int zhat_ld) {
+    DSVC_F16_SAT();
     const int64_t HW = (int64_t)H * W, total = (int64_t)B * C * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i % HW;

@@ -39,6 +39,16 @@ extern "C" int dsvc_set_option(const char* key, int value) {
     return DSVC_E_ARG;
 }
 
+long long g_dsvc_counters[DSVC_CNT_N] = {0};
+extern "C" int64_t dsvc_get_counter(const char* key) {
+    struct { const char* k; int i; } tab[] = {{"conv_generic", DSVC_CNT_GENERIC}, {"conv3x3_pp", DSVC_CNT_PP}, {"conv3x3_ws", DSVC_CNT_WS},
+                                              {"conv1x1", DSVC_CNT_CONV1X1}, {"conv3x3_pp_fused_tail", DSVC_CNT_PP_POST}};
+    for (auto& e : tab)
+        if (key && strcmp(key, e.k) == 0) return (int64_t)__atomic_load_n(&g_dsvc_counters[e.i], __ATOMIC_RELAXED);
+    dsvc_set_error("dsvc_get_counter: unknown key '%s'", key ? key : "(null)");
+    return DSVC_E_ARG;
+}
+
 extern "C" int dsvc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -19,6 +19,7 @@ inline unsigned grid_for(int64_t n) {
 template <int VEC>
 __global__ void warp_kernel(const void* in, int in_ld, int in_dt, const float* flow, int flow_ld,
                             void* out, int out_ld, int out_dt, int B, int H, int W, int C) {
+    DSVC_F16_SAT();
     const int cg = (C + VEC - 1) / VEC;
     const int64_t total = (int64_t)B * H * W * cg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -72,6 +73,7 @@ __global__ void upsample2x_kernel(const float* in, int in_ld, float* out, int ou
 }
 
 __global__ void pool2x2_kernel(int mode, const void* in, int in_ld, void* out, int out_ld, int dt, int B, int H, int W, int C) {
+    DSVC_F16_SAT();
     const int Ho = H / 2, Wo = W / 2;
     const int64_t total = (int64_t)B * Ho * Wo * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -91,6 +93,7 @@ __global__ void pool2x2_kernel(int mode, const void* in, int in_ld, void* out, i
 // 16 bytes per thread (8 f16 / 4 fp32 channels): the element-wise kernel above moves 2-4 bytes per lane (1.5 TB/s at 1080p)
 template <bool H16>
 __global__ void pool2x2_vec_kernel(int mode, const void* in, int in_ld, void* out, int out_ld, int B, int H, int W, int C) {
+    DSVC_F16_SAT();
     constexpr int V = H16 ? 8 : 4;
     const int Ho = H / 2, Wo = W / 2, CV = C / V;
     const int64_t total = (int64_t)B * Ho * Wo * CV;
@@ -136,6 +139,7 @@ __global__ void pool2x2_vec_kernel(int mode, const void* in, int in_ld, void* ou
 
 // nn.PixelShuffle(r) reading NCHW fp32, writing NHWC: out[b][y][x][c] = in[b][c*r*r + (y%r)*r + (x%r)][y/r][x/r]
 __global__ void pixel_shuffle_nchw_kernel(const float* in, void* out, int out_ld, int out_dt, int B, int Co, int Hin, int Win, int r) {
+    DSVC_F16_SAT();
     const int Ho = Hin * r, Wo = Win * r;
     const int64_t total = (int64_t)B * Ho * Wo * Co;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -155,6 +159,7 @@ __global__ void pixel_shuffle_nchw_kernel(const float* in, void* out, int out_ld
 // above wrote 2 bytes per thread at a 32-byte stride (216 us for the 1080p inter-layer feature, ~0.9 TB/s).
 template <bool H16>
 __global__ void pixel_shuffle_nchw_vec8_kernel(const float* __restrict__ in, void* out, int out_ld, int B, int Co, int Hin, int Win, int r) {
+    DSVC_F16_SAT();
     const int64_t total = (int64_t)B * Hin * r * r * Win * (Co / 8);
     const int64_t plane = (int64_t)Hin * Win;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -186,6 +191,7 @@ __global__ void pixel_shuffle_nchw_vec8_kernel(const float* __restrict__ in, voi
 
 // layout transposes through an LDS tile so both sides are coalesced
 __global__ void nchw_to_nhwc_kernel(const float* in, void* out, int out_ld, int out_dt, int B, int C, int64_t HW) {
+    DSVC_F16_SAT();
     __shared__ float tile[32][33];
     const int64_t p0 = (int64_t)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32;
@@ -255,6 +261,7 @@ inline bool vec8_ok(const void* p, int ld, int dt, int C) {
 // warp, 8 channels per thread, 16-B accesses (the 64-channel feature warp of InterLayerPrediction, modules.py:429)
 __global__ void warp8_kernel(const void* in, int in_ld, int in_dt, const float* flow, int flow_ld,
                              void* out, int out_ld, int out_dt, int B, int H, int W, int C) {
+    DSVC_F16_SAT();
     const int cg = C / 8;
     const int64_t total = (int64_t)B * H * W * cg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -285,6 +292,7 @@ __global__ void warp8_kernel(const void* in, int in_ld, int in_dt, const float* 
 // elementwise family, 8 channels per thread (all operands 16-B aligned, C % 8 == 0)
 __global__ void eltwise8_kernel(int op, int64_t n_pix, int C, Opnd a, Opnd b, Opnd c, Opnd d, Opnd e,
                                 void* out, int out_ld, int out_dt) {
+    DSVC_F16_SAT();
     const int cg = C / 8;
     const int64_t total = n_pix * cg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -338,6 +346,7 @@ __global__ void se_partial8_kernel(const void* x, int ld, int dt, int64_t HW, in
 
 __global__ void eltwise_kernel(int op, int64_t n_pix, int C, Opnd a, Opnd b, Opnd c, Opnd d, Opnd e,
                                void* out, int out_ld, int out_dt) {
+    DSVC_F16_SAT();
     const int64_t total = n_pix * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(i % C);

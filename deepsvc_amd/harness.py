@@ -91,7 +91,7 @@ def code_gop(model, frames, sm_feas, unit=0, sync=None, metrics=True, i_model=No
             sm, _ = sm_layer(process(cur * 255.0), supp, mean=True, encode=True)            # test_video.py:336
             supp = torch.cat([supp, sm], 0)[1:]                                             # :338
             if sm_log is not None:
-                sm_log.append((float(sm_layer.bpp_loss) * (cur.shape[-2] * cur.shape[-1]) / (h * w), sm_layer.enct, sm_layer.dect))
+                sm_log.append((float(sm_layer.bpp_loss), sm_layer.enct, sm_layer.dect))     # as the reference takes it (test_video.py:337,366): per PADDED pixel
         else:
             sm = sm_feas[t]
         sync(); t0 = time.perf_counter()
@@ -179,9 +179,9 @@ def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None, overla
 def gather_rows(rows, device, world_size):
     """All ranks' metric rows -> one [n, len(METRIC_COLUMNS)] fp64 CPU tensor on every rank."""
     local = torch.tensor(rows, dtype=torch.float64, device=device).reshape(-1, len(METRIC_COLUMNS))
-    if world_size == 1:
-        return local.cpu()
     import torch.distributed as dist
+    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local.cpu()            # (a one-rank process group still takes the collective path: bench.py DSVC_BENCH_FORCE_PG)
     counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world_size)]
     dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=device))
     n_max = int(max(int(c) for c in counts))
@@ -217,7 +217,7 @@ def reference_results(table, sm_rows=None):
     cols = {n: i for i, n in enumerate(METRIC_COLUMNS)}
     t = table.numpy() if hasattr(table, "numpy") else np.asarray(table)
     out = {k: [] for k in REFERENCE_JSON_KEYS}
-    avg = lambda v: float(np.average(v)) if len(v) else float("nan")
+    avg = lambda v: float(np.average(v)) if len(v) else 0.0      # no I-frame rows (key frame given): 0, so the file stays strict JSON
     for unit in sorted(set(t[:, cols["unit"]].tolist())):
         rows = t[t[:, cols["unit"]] == unit]
         rows = rows[np.argsort(rows[:, cols["frame"]], kind="stable")]

@@ -368,9 +368,24 @@ class ChannelSplitICIP2020ResB(nn.Module):
                     m.__dict__["_epoch_ref"] = ref
         return ref
 
+    def _weights_fingerprint(self):
+        """Sum of the autograd version counters of every parameter of this codec: moves when a weight is edited in place
+        (`p.copy_`, `p.zero_`, optimiser steps) or replaced by load_state_dict.  Recorded scan programs and captured graphs hold
+        pointers to PACKED copies of the weights and never pass through Conv2d._packed again, so this is what invalidates them
+        (tests/test_gpu_model.py::test_weight_edit_invalidates_recorded_scan).  ~10 us per call."""
+        ps = self.__dict__.get("_fp_params")
+        if ps is None:
+            ps = self.__dict__["_fp_params"] = [p for p in self.parameters()]
+        return sum(p._version for p in ps) + (id(ps[0]) if ps else 0)
+
     def _plan(self, B, h, w, device):
         key = (B, h, w, str(device), ops.RT.mode)
         plans = self.__dict__.setdefault("_plans", {})
+        fp = self._weights_fingerprint()
+        if self.__dict__.get("_fp_seen") != fp:          # weights changed since the last call: everything recorded is stale
+            if "_fp_seen" in self.__dict__:
+                self._epoch_ref()[0] += 1
+            self.__dict__["_fp_seen"] = fp
         plan = plans.get(key)
         if plan is None or plan.epoch != self._epoch_ref()[0]:
             if plan is None:
@@ -400,9 +415,13 @@ class ChannelSplitICIP2020ResB(nn.Module):
         if prog is None:
             with ops.ScanRecorder() as rec:
                 fn()                              # executed AND recorded
-            if rec.poisoned is None and self._epoch_ref()[0] == plan.epoch:      # nothing was (re)packed while recording
+            if rec.poisoned is not None:
+                plan.programs[key] = False        # holds an op without a scan-op form: this segment stays launch by launch
+            elif self._epoch_ref()[0] == plan.epoch:      # nothing was (re)packed while recording
                 plan.programs[key] = ops.ScanProgram(rec)
-        elif prog is not False:
+        elif prog is False:
+            fn()
+        else:
             prog.run()
 
     def scan_graphs_ready(self, B, h, w, device):
@@ -589,6 +608,8 @@ class ChannelSplitICIP2020ResB(nn.Module):
                     cur = getattr(mod, n)
                     setattr(mod, n, torch.empty(state_dict[key].shape, dtype=cur.dtype, device=cur.device))
             mod._host_tables = None
+        self.__dict__.pop("_fp_params", None)      # parameters may be replaced objects afterwards
+        self._epoch_ref()[0] += 1                  # recorded scan programs / graphs hold packed copies of the old weights
         return super().load_state_dict(state_dict, strict=strict)
 
     def update(self, scale_table=None, force=False):

@@ -133,6 +133,11 @@ def set_option(key, value):
     return N.check(N.lib().dsvc_set_option(key.encode(), int(value)), "set_option")
 
 
+def get_counter(key):
+    """Launch counter of one conv kernel family (include/dsvc.h: dsvc_get_counter)."""
+    return N.check(N.lib().dsvc_get_counter(key.encode()), "get_counter")
+
+
 def run_parallel(fns):
     """Run independent launch sequences concurrently: branch 0 on the current stream, the others on side streams that
     fork from it and join back.  Eagerly this overlaps tiny latency-bound kernels; under HIP-graph capture the forks
@@ -202,6 +207,7 @@ class Act:
         """Logical NCHW fp32 view/copy for the reference-style API."""
         if self.dtype == torch.float32:
             return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
+        poison_recording("nhwc_to_nchw")          # not a scan-step op
         out = torch.empty((self.B, self.C, self.H, self.W), dtype=torch.float32, device=self.device)
         N.check(N.lib().dsvc_nhwc_to_nchw(_stream(), self.ptr, self.ld, self.code, out.data_ptr(),
                                           self.B, self.C, self.H, self.W), "nhwc_to_nchw")
@@ -227,6 +233,7 @@ def to_act(x, dtype=None):
     xp = x.permute(0, 2, 3, 1)
     if x.dtype == want and xp.is_contiguous():
         return Act(xp)
+    poison_recording("nchw_to_nhwc")          # not a scan-step op
     B, C, H, W = x.shape
     src = x.to(torch.float32).contiguous() if (x.dtype != torch.float32 or not x.is_contiguous()) else x
     out = new_act(B, H, W, C, want, x.device)
@@ -549,6 +556,7 @@ def reduce(mode, a, b=None):
 def ssim_level(x, y, data_range=1.0):
     """One MS-SSIM level -> (ssim[B*C], cs[B*C]) fp32 device vectors (include/dsvc.h: dsvc_ssim_level)."""
     assert (x.B, x.H, x.W, x.C) == (y.B, y.H, y.W, y.C)
+    poison_recording("ssim_level")          # not a scan-step op
     L = N.lib()
     ws = torch.empty(max(L.dsvc_ssim_workspace_floats(x.B, x.H, x.W, x.C), 1), dtype=torch.float32, device=x.device)
     out = torch.empty((2, x.B * x.C), dtype=torch.float32, device=x.device)
@@ -559,6 +567,7 @@ def ssim_level(x, y, data_range=1.0):
 
 def avgpool2_pad(x):
     """F.avg_pool2d(x, 2, padding=(H % 2, W % 2)) -> dense fp32 Act."""
+    poison_recording("avgpool2_pad")          # not a scan-step op
     Ho, Wo = (x.H + 2 * (x.H & 1) - 2) // 2 + 1, (x.W + 2 * (x.W & 1) - 2) // 2 + 1
     out = new_act(x.B, Ho, Wo, x.C, torch.float32, x.device)
     N.check(N.lib().dsvc_avgpool2_pad(_stream(), _op(x), out.ptr, x.B, x.H, x.W, x.C), "avgpool2_pad")

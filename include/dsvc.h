@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_VERSION 1
+#define DSVC_VERSION 2   /* 2: binary16 (not bfloat16) is dtype code 1; scan ops, refine_aggregate, counters; f16 stores saturate */
 
 /* error codes */
 #define DSVC_OK 0
@@ -59,6 +59,10 @@ int dsvc_device_count(void);
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);
+/* Diagnostic: how many dsvc_conv2d launches each kernel family has taken since the library was loaded (process-wide).
+ * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1".  Tests use it to prove that the
+ * large-image kernels ran inside a frame that is checked against the reference.  Returns DSVC_E_ARG for an unknown key. */
+int64_t dsvc_get_counter(const char* key);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution family (one MFMA implicit-GEMM kernel, fused epilogue).

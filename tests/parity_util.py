@@ -83,3 +83,40 @@ def product_latent(codec, h, w, device):
     """y_hat [1,M,h,w] the last encode/decode of `codec` left in its scan workspace."""
     ws = codec._plan(1, h, w, torch.device(device))
     return ws.y_hat.nchw().float().cpu().clone()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# full-size fixtures (tests/golden/make_golden_full.py): strided samples + block means (cover every pixel) + fp64 sums
+# ------------------------------------------------------------------------------------------------------------
+def line_crcs(plane):
+    """int array [C, h, w] -> uint32 [C, h]: CRC-32 of every line as little-endian int32 (as make_golden_full.py stores them)."""
+    import zlib
+    a = np.ascontiguousarray(np.asarray(plane).astype("<i4"))
+    C, h, _ = a.shape
+    return np.asarray([[zlib.crc32(a[c, y].tobytes()) for y in range(h)] for c in range(C)], dtype=np.uint32)
+
+
+def golden_full_errors(g, key, t):
+    """Tensor `t` against a make_golden_full.py entry -> (rel-L2 on the strided samples, rel-L2 on the block means, relative error of
+    the sum of squares).  The block means see every element of the tensor."""
+    a = t.detach().float().cpu().numpy()
+    shape = tuple(int(v) for v in g[key + "/shape"])
+    assert tuple(a.shape) == shape, f"{key}: shape {a.shape} vs golden {shape}"
+    stride, blk = int(g[key + "/stride"][0]), int(g[key + "/blk"][0])
+    rel = lambda x, y: float(np.linalg.norm((x.astype(np.float64) - y.astype(np.float64))) / max(np.linalg.norm(y.astype(np.float64)), 1e-30))
+    e_s = rel(a[..., ::stride, ::stride], g[key + "/data"])
+    *lead, H, W = a.shape
+    bm = a.astype(np.float64).reshape(*lead, H // blk, blk, W // blk, blk).mean(axis=(-3, -1))
+    e_b = rel(bm, g[key + "/blockmean"])
+    s2 = float((a.astype(np.float64) ** 2).sum())
+    e_q = abs(s2 - float(g[key + "/stats"][1])) / max(float(g[key + "/stats"][1]), 1e-30)
+    return e_s, e_b, e_q
+
+
+def check_golden_full(g, key, t, rel, label=None):
+    e_s, e_b, e_q = golden_full_errors(g, key, t)
+    print(f"[parity] {label or key}: samples rel-L2 {e_s:.2e}, block means rel-L2 {e_b:.2e}, sum of squares {e_q:.2e}")
+    assert e_s <= rel, f"{key}: strided samples off the reference's by {e_s:.3e} (> {rel:.1e})"
+    assert e_b <= rel, f"{key}: block means off the reference's by {e_b:.3e} (> {rel:.1e})"
+    assert e_q <= 4 * rel, f"{key}: sum of squares off the reference's by {e_q:.3e}"
+    return e_s

@@ -136,3 +136,27 @@ def test_bench_launches_its_own_ranks_on_the_gpu_box():
     assert len(lines) == 1, f"stdout must carry exactly the JSON line, got {len(lines)} lines"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["frames_per_step"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_rank_body_runs_on_rccl_at_world_size_one():
+    """The multi-GPU run itself is the driver's (a whole 8-GPU node); what can be proven on the one-GPU box is that the RCCL code
+    path executes: `bench.py` as ONE rank of a `backend="nccl"` process group (fresh child process: RANK=0, WORLD_SIZE=1,
+    DSVC_BENCH_FORCE_PG=1) -- init_process_group(device_id=...), barrier, all_reduce(MAX) on a HIP tensor and harness.gather_rows'
+    all_gather all go through RCCL."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DSVC_BENCH_FORCE_PG="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("DSVC_BENCH_REHEARSAL", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--size", "256x256", "--steps", "2", "--warmup", "1",
+                        "--lanes", "2", "--no-cpu-baseline", "--no-side-legs"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 0
+    assert d["config"]["bpp"] > 0, "the metric rows did not come back through the RCCL all_gather"

@@ -310,3 +310,75 @@ def test_gop_lanes_match_sequential_coding():
             assert a[:7] == b[:7], (a[:7], b[:7])            # unit, frame, bpp_mv, bpp_res, psnr x3: bit-identical results
     finally:
         ops.set_precision("fp32")
+
+
+def test_weight_edit_invalidates_recorded_scan():
+    """recorded scan programs / HIP graphs hold pointers to PACKED copies of the weights and never pass through
+    Conv2d._packed on replay.  After an in-place weight edit (or load_state_dict) on a warmed model, a decompress-only call must
+    see the new weights: the decoded latents change, and they equal those of a fresh model with the edited weights."""
+    from deepsvc_amd import ops, synth
+    ops.set_precision("fp32")
+    fr, sm = synth.make_frames(64, 64, 2), synth.make_sm_fea(64, 64, 1).to(DEV)
+    m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+    mv, res = m.compress(fr[0].to(DEV), fr[1].to(DEV), sm, None)
+    mv, res = dict(mv.items()), dict(res.items())
+    for _ in range(3):                     # warm: programs recorded, graphs captured
+        base = m.decompress(fr[0].to(DEV), mv, res, sm, None)
+    base_lat = m.mv_codec._plan(1, 4, 4, torch.device(DEV)).y_hat.buf.clone()
+
+    def edited(model):
+        with torch.no_grad():              # the last conv of the mv codec's first LRP stack: feeds y_hat directly
+            model.mv_codec.lrp_transforms[0][4].weight.mul_(3.0)
+            model.mv_codec.lrp_transforms[0][4].bias.add_(0.25)
+
+    edited(m)
+    after = m.decompress(fr[0].to(DEV), mv, res, sm, None)           # decompress ONLY: no conv of this codec ran eagerly in between
+    after_lat = m.mv_codec._plan(1, 4, 4, torch.device(DEV)).y_hat.buf.clone()
+    assert not torch.equal(after_lat, base_lat), "the replayed scan ignored the weight edit"
+    fresh = synth.make_model("W0"); fresh.update(force=True); fresh = fresh.to(DEV)
+    edited(fresh)
+    want = fresh.decompress(fr[0].to(DEV), mv, res, sm, None)
+    want_lat = fresh.mv_codec._plan(1, 4, 4, torch.device(DEV)).y_hat.buf
+    assert torch.equal(after_lat, want_lat) and torch.equal(after[1], want[1])
+    # load_state_dict on a warmed model: back to the original weights -> the original output, bit for bit
+    sd = {k: v.clone() for k, v in synth.make_model("W0").state_dict().items()}
+    m.load_state_dict(sd)
+    m.update(force=True)
+    again = m.decompress(fr[0].to(DEV), mv, res, sm, None)
+    assert torch.equal(again[1], base[1]) and torch.equal(again[0].float(), base[0].float())
+
+
+def test_replayed_scan_equals_eager_issue():
+    """The recorded scan step (one C call per segment) and the captured HIP graph replay the launches the eager path issues: staging
+    symbols / indexes and y_hat are bit-identical between a model that never records (DSVC_NO_SCAN_STEP / DSVC_NO_GRAPHS behaviour)
+    and a warmed model on its 2nd..4th call."""
+    from deepsvc_amd import ops, synth
+    import parity_util as PU
+    for mode in ("fp32", "f16"):
+        ops.set_precision(mode)
+        try:
+            fr, sm = synth.make_frames(128, 128, 2), synth.make_sm_fea(128, 128, 1).to(DEV)
+            outs = {}
+            for name, (step, graphs) in (("eager", (False, False)), ("replayed", (True, True))):
+                old = ops.SCAN_STEP[0], ops.USE_GRAPHS[0]
+                ops.SCAN_STEP[0], ops.USE_GRAPHS[0] = step, graphs
+                try:
+                    m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+                    for _ in range(4):
+                        mv, res = m.compress(fr[0].to(DEV), fr[1].to(DEV), sm, None)
+                        mv, res = dict(mv.items()), dict(res.items())
+                        enc_planes = [np.concatenate(PU.product_symbol_planes(c, 8, 8, DEV)) for c in (m.mv_codec, m.res_codec)]
+                        dec = m.decompress(fr[0].to(DEV), mv, res, sm, None)
+                    if graphs:
+                        assert m.graphs_ready(1, 128, 128, torch.device(DEV))
+                    lat = [c._plan(1, 8, 8, torch.device(DEV)).y_hat.buf.clone() for c in (m.mv_codec, m.res_codec)]
+                    outs[name] = (mv, res, enc_planes, lat, dec[1].clone(), dec[0].float().clone())
+                finally:
+                    ops.SCAN_STEP[0], ops.USE_GRAPHS[0] = old
+            a, b = outs["eager"], outs["replayed"]
+            assert a[0]["strings"] == b[0]["strings"] and a[1]["strings"] == b[1]["strings"]
+            assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+            assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+            assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+        finally:
+            ops.set_precision("fp32")

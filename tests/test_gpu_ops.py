@@ -708,3 +708,38 @@ def test_entropy_bottleneck_kernels():
     strings = eb.compress(z.to(DEV))
     assert strings == E.eb_compress(sd, "", E.eb_tables(sd, ""), z)
     report_close("eb decompress", eb.decompress(strings, (5, 6)).cpu(), zh_want, 0, 1e-6)
+
+
+def test_f16_stores_saturate():
+    """binary16 tops out at 65504; every kernel that stores f16 runs with MODE.FP16_OVFL set (csrc/common.h: DSVC_F16_SAT), so an
+    out-of-range activation is stored as +-65504 instead of +-inf -- through the conv epilogues (generic, ping-pong, 1x1), the
+    layout kernels and the element-wise kernels -- and NaN / true infinities are not hidden."""
+    from deepsvc_amd import _native as N, ops
+    from deepsvc_amd.modules import Conv2d
+    ops.set_precision("f16")
+    try:
+        torch.manual_seed(0)
+        for k, H, W in ((3, 16, 32), (3, 256, 1024), (1, 256, 1024), (1, 8, 8)):     # generic / ping-pong / direct 1x1 / generic 1x1
+            m = Conv2d(64, 64, k, 1, padding=k // 2)
+            with torch.no_grad():
+                m.weight.fill_(0.0)
+                m.weight[:, 0, k // 2, k // 2] = 1.0
+                m.bias.fill_(0.0)
+            x = torch.zeros(1, 64, H, W)
+            x[0, 0, 3, 5], x[0, 0, 4, 6], x[0, 0, 5, 7] = 60000.0, -60000.0, 1.0     # representable in f16
+            with torch.no_grad():
+                m.weight[:, 0, k // 2, k // 2] = 4.0                                      # 240000: above the f16 range
+            out = m.to(DEV).run(_act(x, torch.float16), out_dtype=torch.float16)
+            o = out.nchw().cpu()
+            assert bool(torch.isfinite(o).all()), f"k={k} {H}x{W}: non-finite f16 store"
+            assert float(o[0, 7, 3, 5]) == 65504.0 and float(o[0, 7, 4, 6]) == -65504.0 and float(o[0, 7, 5, 7]) == 4.0, (k, H, W, o[0, 7, 3, 5])
+        # layout conversion and element-wise kernels
+        big = torch.full((1, 8, 4, 8), 1.0e6)
+        a = ops.to_act(big.to(DEV), torch.float16)
+        assert float(a.buf.float().max()) == 65504.0
+        s = ops.eltwise(N.EW_ADD, a, a, out_dtype=torch.float16)
+        assert float(s.buf.float().max()) == 65504.0 and bool(torch.isfinite(s.buf.float()).all())
+        nan = torch.full((1, 8, 4, 8), float("nan"))
+        assert bool(torch.isnan(ops.to_act(nan.to(DEV), torch.float16).buf.float()).all()), "NaN must stay NaN"
+    finally:
+        ops.set_precision("fp32")
