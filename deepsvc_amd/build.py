@@ -32,12 +32,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile each source to an object (only when stale) and link libdsvc.so.  Returns the path."""
+def build(force=False, verbose=False, variant=None, defines=()):
+    """Compile each source to an object (only when stale) and link libdsvc.so.  Returns the path.
+    variant="clock", defines=["-DDSVC_PP_CLOCK"]: a diagnostic build next to the product one (lib/libdsvc_clock.so, own object
+    directory), loaded with DSVC_LIB=... by the tools that read its probes."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    obj_dir = os.path.join(LIB_DIR, "obj" if variant is None else f"obj_{variant}")
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
+    LIB = os.path.join(LIB_DIR, "libdsvc.so" if variant is None else f"libdsvc_{variant}.so")
+    FLAGS = globals()["FLAGS"] + list(defines)
     objs, relink = [], force or not os.path.exists(LIB)
     procs = []
     for src in SOURCES:
@@ -63,4 +67,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m deepsvc_amd.build [--force] [--variant NAME -DFOO -DBAR ...]
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose=True, variant=var, defines=[a for a in sys.argv[1:] if a.startswith("-D")]))

@@ -571,10 +571,13 @@ class ChannelSplitICIP2020ResB(nn.Module):
         groups, n = ws.groups, ws.ns
         steps = self._segments(ws)
         self._step(ws, "dec0", steps["dec0"])
+        idx_taps = self.__dict__.get("debug_idx_taps")      # tests only: the index planes the decoder looked its CDFs up with, level by level
         for k, group in enumerate(groups):
             m = len(group) * n
             ws.idx_host[:m].copy_(ws.idx_dev[:m], non_blocking=True)
             stream.synchronize()                 # the one sync point of this level
+            if idx_taps is not None:
+                idx_taps.append(ws.idx_host[:m].clone())
             dec.decode_stream(ws.idx_host.numpy()[:m], tables, out=ws.sym_host.numpy()[:m])
             ws.sym_dev[:m].copy_(ws.sym_host[:m], non_blocking=True)
             self._step(ws, f"dec{k + 1}", steps[f"dec{k + 1}"])

@@ -55,24 +55,42 @@ def compact_full(name, t, out, stride, blk):
     out[name + "/blockmean"] = block_means(a, blk)
 
 
+SYM_MARGIN, IDX_MARGIN = 3e-4, 3e-4      # what counts as a "fragile" decision worth listing (the tests use tighter thresholds)
+
+
 class Tap:
-    """Records what a codec's GaussianConditional stand-in returns while the reference's compress() runs: the symbol planes
-    (`quantize`, image_model.py:237) and the index planes (`build_indexes`, image_model.py:238)."""
+    """Records what a codec's GaussianConditional stand-in sees while the reference's compress() runs: the symbol planes
+    (`quantize`, image_model.py:237), the index planes (`build_indexes`, image_model.py:238), and how close each of those hard
+    decisions was to going the other way: `round(y - mu)` at distance |frac(y - mu) - 0.5| from a rounding boundary, the scale-table
+    lookup at relative distance min_k |sigma - table[k]| / table[k] from a table level.  A conforming fp32 implementation with
+    another summation order (any GPU) can only differ from the reference at such fragile positions -- and downstream of them."""
 
     def __init__(self, gc):
-        self.gc, self.on, self.sym, self.idx = gc, False, [], []
+        self.gc, self.on, self.sym, self.idx, self.sym_frag, self.idx_frag = gc, False, [], [], [], []
         q0, b0 = gc.quantize, gc.build_indexes
+        table = MG.E.get_scale_table().double()
 
         def quantize(x, mode, means=None):
             r = q0(x, mode, means)
             if self.on:
+                c0 = sum(s.shape[1] for s in self.sym)
                 self.sym.append(r.detach().cpu().numpy())
+                v = (x - means).detach().double()[0]
+                margin = ((v - torch.floor(v)) - 0.5).abs()
+                scale = (x.abs() + means.abs()).detach().double()[0]
+                c, yy, xx = torch.nonzero(margin < SYM_MARGIN * (1.0 + scale), as_tuple=True)
+                self.sym_frag.append(torch.stack([(c + c0).double(), yy.double(), xx.double(), margin[c, yy, xx], scale[c, yy, xx]], 1).numpy())
             return r
 
         def build_indexes(scales):
             r = b0(scales)
-            if self.on:
+            if self.on and len(self.idx) < 64:
+                c0 = sum(s.shape[1] for s in self.idx)
                 self.idx.append(r.detach().cpu().numpy())
+                sg = scales.detach().double()[0]          # un-clamped: sigma <= 0.11 is clamped to table[0] and lands on index 0 robustly;
+                rel = ((sg[..., None] - table[:-1]) / table[:-1]).abs().min(-1).values      # the decision boundaries are table[0..62]
+                c, yy, xx = torch.nonzero(rel < IDX_MARGIN, as_tuple=True)
+                self.idx_frag.append(torch.stack([(c + c0).double(), yy.double(), xx.double(), rel[c, yy, xx]], 1).numpy())
             return r
 
         gc.quantize, gc.build_indexes = quantize, build_indexes
@@ -81,8 +99,19 @@ class Tap:
         n = len(self.sym)  # compress() quantises every slice once; later build_indexes calls belong to decompress()
         sym = np.concatenate([s[0] for s in self.sym], axis=0)
         idx = np.concatenate([s[0] for s in self.idx[:n]], axis=0)
-        self.sym, self.idx = [], []
-        return sym, idx
+        sf = np.concatenate(self.sym_frag, 0).astype(np.float32)
+        jf = np.concatenate(self.idx_frag[:n], 0).astype(np.float32)
+        jf = jf[jf[:, 0] < sym.shape[0]]
+        self.sym, self.idx, self.sym_frag, self.idx_frag = [], [], [], []
+        return sym, idx, sf, jf
+
+
+def store_planes(out, pre, sym, idx, sf, jf):
+    out[pre + "_sym_crc"], out[pre + "_idx_crc"] = line_crcs(sym), line_crcs(idx)
+    assert np.abs(sym).max() < 32768 and idx.min() >= 0 and idx.max() < 256
+    out[pre + "_sym"], out[pre + "_idx"] = sym.astype(np.int16), idx.astype(np.uint8)
+    out[pre + "_sym_fragile"], out[pre + "_idx_fragile"] = sf, jf      # rows (channel, y, x, margin, |y|+|mu|) / (channel, y, x, relative margin)
+    out[pre + "_sym_hist"] = np.bincount(np.clip(sym.reshape(-1) + 64, 0, 128), minlength=129).astype(np.int64)
 
 
 def p_frames(ref_model, H, W, n_p, out, tag, stride3, stride64, blk3, blk64, features_of):
@@ -101,10 +130,7 @@ def p_frames(ref_model, H, W, n_p, out, tag, stride3, stride64, blk3, blk64, fea
             for tp in taps.values():
                 tp.on = False
             for nm, tp in taps.items():
-                sym, idx = tp.planes()
-                out[f"{tag}/f{t}/enc/{nm}_sym_crc"] = line_crcs(sym)
-                out[f"{tag}/f{t}/enc/{nm}_idx_crc"] = line_crcs(idx)
-                out[f"{tag}/f{t}/enc/{nm}_sym_hist"] = np.bincount(np.clip(sym.reshape(-1) + 64, 0, 128), minlength=129).astype(np.int64)
+                store_planes(out, f"{tag}/f{t}/enc/{nm}", *tp.planes())
             feature, recon, warped, predict = ref_model.decompress(ref_frame, mv, res, sm, feature)
             t2 = time.time()
             times.append((t1 - t0, t2 - t1))
@@ -162,11 +188,11 @@ def main():
             enc = icip.compress(x)
             t1 = time.time()
             tap.on = False
-            sym, idx = tap.planes()
+            planes = tap.planes()
             dec = icip.decompress(enc["strings"], enc["shape"])
             t2 = time.time()
         print(f"icip 1080p: reference compress {t1 - t0:.1f} s, decompress {t2 - t1:.1f} s", flush=True)
-        out["icip1080/enc/sym_crc"], out["icip1080/enc/idx_crc"] = line_crcs(sym), line_crcs(idx)
+        store_planes(out, "icip1080/enc/y", *planes)
         out["icip1080/enc/y"] = np.frombuffer(enc["strings"][0][0], dtype=np.uint8)
         out["icip1080/enc/z"] = np.frombuffer(enc["strings"][1][0], dtype=np.uint8)
         out["icip1080/enc/shape"] = np.asarray(enc["shape"], dtype=np.int64)

@@ -120,3 +120,74 @@ def check_golden_full(g, key, t, rel, label=None):
     assert e_b <= rel, f"{key}: block means off the reference's by {e_b:.3e} (> {rel:.1e})"
     assert e_q <= 4 * rel, f"{key}: sum of squares off the reference's by {e_q:.3e}"
     return e_s
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# hard decisions at full size: where a conforming fp32 implementation may legitimately differ from the reference
+# ------------------------------------------------------------------------------------------------------------------------
+def _dilate(mask, r):
+    if r <= 0 or not mask.any():
+        return mask.copy()
+    t = torch.from_numpy(mask[None, None].astype(np.float32))
+    return torch.nn.functional.max_pool2d(t, 2 * r + 1, stride=1, padding=r)[0, 0].numpy() > 0
+
+
+def explain_plane_mismatches(g, pre, sym, idx, slice_depth, max_support, sym_tol=2e-5, idx_tol=2e-5, radius=7, seed=None):
+    """The GPU encoder's symbol / index planes [M, h, w] against the REFERENCE's (full planes + list of fragile decisions stored by
+    tests/golden/make_golden_full.py).  The channel-conditional scan rounds `y - mu` and looks sigma up in a 64-level table, slice after
+    slice; two fp32 implementations with different summation orders (oneDNN on the CPU, MFMA on the GPU: ~1e-6 relative apart) can
+    only disagree where the reference's own decision was within that distance of flipping (a ROOT), and then wherever a root's
+    altered y_hat reaches through the 3x3 stacks of the later slices (4 convs for mu / sigma, 3 for the latent residual prediction:
+    <= `radius` latent pixels per slice level; only the first `max_support` slices feed others, image_model.py:227).  `seed`: latent
+    pixels [h, w] whose INPUT already differs (the residual codec codes a picture predicted with the motion codec's output, so the
+    motion codec's mismatches seed it).
+    Walks the slices in dependency order and classifies every mismatch as root (listed as fragile with margin <= tol), downstream
+    of a root, or UNEXPLAINED.  -> dict(symbols, indexes, roots, root_margins, unexplained, lines)"""
+    ref_sym, ref_idx = g[pre + "_sym"].astype(np.int32), g[pre + "_idx"].astype(np.int32)
+    sym, idx = np.asarray(sym, dtype=np.int32).reshape(ref_sym.shape), np.asarray(idx, dtype=np.int32).reshape(ref_idx.shape)
+    M, h, w = ref_sym.shape
+    fs, fi = g[pre + "_sym_fragile"], g[pre + "_idx_fragile"]
+    frag_s = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) / (1.0 + float(r[4])) for r in fs}       # margin relative to 1 + |y| + |mu|
+    frag_i = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) for r in fi}
+    contaminated = np.zeros((h, w), dtype=bool) if seed is None else seed.copy()   # latent pixels where a support slice's y_hat (or the input) differs
+    roots, unexplained, n_sym, n_idx = [], [], 0, 0
+    for i in range(M // slice_depth):
+        c0 = i * slice_depth
+        ms, mi = sym[c0:c0 + slice_depth] != ref_sym[c0:c0 + slice_depth], idx[c0:c0 + slice_depth] != ref_idx[c0:c0 + slice_depth]
+        n_sym, n_idx = n_sym + int(ms.sum()), n_idx + int(mi.sum())
+        both = ms | mi
+        if both.any():
+            zone = _dilate(contaminated, radius)
+            for c, y, x in zip(*np.nonzero(both & ~zone[None])):
+                key = (c0 + int(c), int(y), int(x))
+                m_s = frag_s.get(key) if ms[c, y, x] else None
+                m_i = frag_i.get(key) if mi[c, y, x] else None
+                if (m_s is not None and m_s <= sym_tol) or (m_i is not None and m_i <= idx_tol):
+                    roots.append((key, "symbol" if m_s is not None and m_s <= sym_tol else "index", m_s if m_s is not None else m_i))
+                else:
+                    unexplained.append((key, bool(ms[c, y, x]), bool(mi[c, y, x]), m_s, m_i))
+        if i < max_support:
+            contaminated = _dilate(contaminated, radius) | both.any(0)
+    lines = int((line_crcs(sym) != line_crcs(ref_sym)).sum()), int((line_crcs(idx) != line_crcs(ref_idx)).sum())
+    where = ((sym != ref_sym) | (idx != ref_idx)).any(0)
+    return dict(symbols=n_sym, indexes=n_idx, total=int(sym.size), roots=roots, unexplained=unexplained, lines=lines, where=where)
+
+
+def first_decoder_index_mismatch(g, pre, idx_taps, groups, slice_depth, h, w):
+    """The index planes the GPU decoder used (level by level: ChannelSplitICIP2020ResB.debug_idx_taps) while decoding the REFERENCE's
+    string, against the reference's index planes, in bitstream order.  -> None when every CDF lookup matched (the decode is then the
+    reference's decode, symbol for symbol), else ((channel, y, x), reference margin of that decision or None, symbols decoded correctly
+    before it): the range decoder is desynchronised from there on -- one wrong CDF shifts its state for the rest of the stream."""
+    ref_idx = g[pre + "_idx"].astype(np.int32)
+    frag = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) for r in g[pre + "_idx_fragile"]}
+    done = 0
+    for level, group in zip(idx_taps, groups):
+        got = level.numpy().reshape(len(group) * slice_depth, h, w)
+        want = np.concatenate([ref_idx[i * slice_depth:(i + 1) * slice_depth] for i in group], 0)
+        bad = np.nonzero((got != want).reshape(-1))[0]
+        if bad.size:
+            c, y, x = np.unravel_index(int(bad[0]), got.shape)
+            ch = group[int(c) // slice_depth] * slice_depth + int(c) % slice_depth
+            return (ch, int(y), int(x)), frag.get((ch, int(y), int(x))), done + int(bad[0])
+        done += got.size
+    return None
