@@ -650,8 +650,13 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
 
 template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false>
 int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, float pre_slope) {
-    if constexpr (!M16 && !HEAD) {             // option "pp16" (default 1): the 16x16x32 MFMA shape for everything but the narrow heads
-        if (g_dsvc_opt.pp16) return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, true>(st, p, ntiles, act_slope, pre_slope);
+    if constexpr (!M16 && !HEAD) {
+        // option "pp16": 0 = 32x32x16 everywhere, 2 = 16x16x32 everywhere but the narrow heads, 1 (default) = where it measured faster
+        // on the same box (tools/bench_pp16.py, 1088x1920, three interleaved rounds): one residual 187 -> 179 us, fused 1x1 tail
+        // 212 -> 202 us; slower or equal elsewhere (plain 152 -> 153, pre + act 165 -> 174, two residuals 235 -> 254, 64 -> 32 99 -> 103)
+        const bool faster16 = NCH == 2 && NT == 2 && !PRE && HAS_R1 && !HAS_R2;
+        if (g_dsvc_opt.pp16 == 2 || (g_dsvc_opt.pp16 == 1 && faster16))
+            return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, true>(st, p, ntiles, act_slope, pre_slope);
     }
     const size_t lds = (size_t)NCH * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)2 * NT * 32 * sizeof(float) +
                        (POST ? (size_t)NT * NT * 32 * ROWB : 0);

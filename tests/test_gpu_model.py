@@ -382,3 +382,69 @@ def test_replayed_scan_equals_eager_issue():
             assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
         finally:
             ops.set_precision("fp32")
+
+
+def test_4k_fp32_p_frame_round_trip():
+    """BASELINE.json config 5 size at the reference's precision: one 2176x3840 P-frame in fp32 mode (a 64-channel fp32 activation
+    is 2.139 GB: just under the 2 GiB extent a buffer resource addresses).  Encode -> decode round trip: decoder latents ==
+    encoder latents, deterministic decode; and f16 mode on the same inputs stays within the north-star tolerance of it."""
+    from deepsvc_amd import ops, synth
+    from deepsvc_amd.modules import pad
+    import parity_util as PU
+    res = {}
+    try:
+        for mode in ("fp32", "f16"):
+            ops.set_precision(mode)
+            m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+            frames = [pad(f.to(DEV), 64) for f in synth.make_frames(2160, 3840, 2, seed=3)]
+            sm = synth.make_sm_fea(2176, 3840, 1, seed=3).to(DEV)
+            mv, rs = m.compress(frames[0], frames[1], sm, None)
+            mv, rs = dict(mv.items()), dict(rs.items())
+            torch.cuda.synchronize()
+            dev = torch.device(DEV)
+            enc_lat = [c._plan(1, 136, 240, dev).y_hat.buf.clone() for c in (m.mv_codec, m.res_codec)]
+            m.debug_taps = {}
+            f1, r1, _, _ = m.decompress(frames[0], mv, rs, sm, None)
+            raw = m.debug_taps["recon"].float().cpu()
+            m.debug_taps = None
+            torch.cuda.synchronize()
+            dec_lat = [c._plan(1, 136, 240, dev).y_hat.buf.clone() for c in (m.mv_codec, m.res_codec)]
+            assert all(torch.equal(a, b) for a, b in zip(enc_lat, dec_lat)), f"{mode}: decoder latents differ from the encoder's"
+            if mode == "fp32":
+                f2, r2, _, _ = m.decompress(frames[0], mv, rs, sm, None)
+                assert torch.equal(r1, r2) and torch.equal(f1, f2)
+            nbytes = sum(len(s[0]) for e in (mv, rs) for s in e["strings"])
+            psnr = float(-10 * torch.log10(((r1 - frames[1]) ** 2).mean()))
+            print(f"4K {mode}: {nbytes} B = {nbytes * 8 / (2160 * 3840):.3f} bpp, PSNR {psnr:.3f} dB, peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+            assert torch.isfinite(r1).all() and psnr > 20
+            res[mode] = (nbytes, psnr, raw, f1.float().cpu())
+            del m, frames, f1, r1, enc_lat, dec_lat
+            torch.cuda.empty_cache()
+    finally:
+        ops.set_precision("fp32")
+    (na, pa, ra, fa), (nb, pb, rb, fb) = res["fp32"], res["f16"]
+    e_rec, e_fea = PU.rel_l2(rb, ra), PU.rel_l2(fb, fa)
+    print(f"4K f16 vs fp32: bytes {100.0 * (nb - na) / na:+.3f} %, PSNR {pb - pa:+.4f} dB, un-clamped recon rel-L2 {e_rec:.2e}, feature {e_fea:.2e}")
+    assert abs(nb - na) <= 0.01 * na and abs(pb - pa) <= 0.05 and e_rec <= PU.F16_BOUNDS["recon"] and e_fea <= PU.F16_BOUNDS["feature"]
+
+
+def test_4k_gop12_with_intra_key_frame_f16():
+    """BASELINE.json config 5 on one GPU (its 8-GPU leg shards GOPs like every other config): 3840x2160, GOP = 12, key frame coded
+    by ICIP2020ResB, 11 chained P-frames, f16 mode, whole (un-tiled) frames.  Every frame round-trips (harness.code_gop decodes what
+    it encoded), rates and PSNRs are sane and the chain does not drift into non-finite values."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("f16")
+    try:
+        m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+        im = synth.make_icodec("W0"); im.update(force=True); im = im.to(DEV)
+        frames = [f.to(DEV) for f in synth.make_frames(2160, 3840, 12, seed=5)]
+        sms = [None] + [synth.make_sm_fea(2176, 3840, t, seed=5).to(DEV) for t in range(1, 12)]
+        rows = harness.code_gop(m, frames, sms, unit=0, sync=torch.cuda.synchronize, metrics=True, i_model=im)
+        assert len(rows) == 12
+        t = torch.tensor([r[:9] for r in rows], dtype=torch.float64)
+        bpp = t[:, 2] + t[:, 3]
+        print("4K GOP12: bpp per frame", [f"{v:.3f}" for v in bpp.tolist()], "PSNR", [f"{v:.2f}" for v in t[:, 4].tolist()],
+              f"t_enc+t_dec per P-frame {float((t[1:, 7] + t[1:, 8]).mean()) * 1e3:.1f} ms, peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+        assert bool(torch.isfinite(t).all()) and float(bpp.min()) > 0.05 and float(t[1:, 4].min()) > 8.0
+    finally:
+        ops.set_precision("fp32")

@@ -743,3 +743,44 @@ def test_f16_stores_saturate():
         assert bool(torch.isnan(ops.to_act(nan.to(DEV), torch.float16).buf.float()).all()), "NaN must stay NaN"
     finally:
         ops.set_precision("fp32")
+
+
+def test_pp_kernel_mfma_shapes_agree():
+    """The two-group 3x3 kernel exists on two MFMA shapes (option pp16: 0 = 32x32x16, 2 = 16x16x32; different lane layouts, LDS
+    read pattern, epilogue swaps and residual layout, same arithmetic): every epilogue variant gives bit-identical f16 outputs on
+    both, except the fused 1x1 tail, whose second GEMM sums K = 64 in two steps instead of four (<= one f16 ulp apart).  The
+    32x32x16 side is held against F.conv2d by the tests above."""
+    from deepsvc_amd import _native as N, ops
+    from deepsvc_amd.modules import Conv2d
+    ops.set_precision("f16")
+    h = torch.float16
+    try:
+        torch.manual_seed(3)
+        H, W = 264, 1000                      # ragged: 33 tile rows, the last tile column 8 pixels wide; 1056 tiles
+        x = ops.Act(torch.randn((1, H, W, 64), device=DEV).to(h))
+        x32 = ops.Act(torch.randn((1, H, W, 32), device=DEV).to(h))
+        r1, r2 = ops.Act(torch.randn((1, H, W, 64), device=DEV).to(h)), ops.Act(torch.randn((1, H, W, 64), device=DEV).to(h))
+        r32 = ops.Act(torch.randn((1, H, W, 32), device=DEV).to(h))
+        c64, c32, c1 = Conv2d(64, 64, 3, 1, 1).to(DEV), Conv2d(64, 32, 3, 1, 1).to(DEV), Conv2d(32, 64, 3, 1, 1).to(DEV)
+        post = Conv2d(64, 64, 1, 1, 0).to(DEV)._packed([64], DEV)
+        cases = [("plain", c64, x, {}), ("act", c64, x, dict(act=N.ACT_LRELU, slope=0.1)), ("pre+act relu", c64, x, dict(pre_act=N.ACT_RELU, act=N.ACT_RELU, slope=0.0)),
+                 ("pre lrelu", c64, x, dict(pre_act=N.ACT_LRELU, slope=0.01)), ("res1", c64, x, dict(res1=r1)),
+                 ("act+res1+res2", c64, x, dict(act=N.ACT_LRELU, slope=0.01, res1=r1, res2=r2)),
+                 ("64->32 + res", c32, x, dict(res1=r32)), ("32->64", c1, x32, dict(act=N.ACT_RELU)),
+                 ("fused tail", c64, x, dict(act=N.ACT_LRELU, slope=0.01, res1=r1, post=post))]
+        for name, m, inp, kw in cases:
+            outs = []
+            for opt in (0, 2):
+                ops.set_option("pp16", opt)
+                before = ops.get_counter("conv3x3_pp")
+                outs.append(m.run(inp, out_dtype=h, **kw).buf.float().cpu())
+                assert ops.get_counter("conv3x3_pp") == before + 1, f"{name}: the two-group kernel did not take this launch"
+            a, b = outs
+            assert bool(torch.isfinite(b).all())
+            if "post" in kw:
+                close_f16(f"pp16 {name}", b, a, both_f16=True)
+            else:
+                assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ between the MFMA shapes, max {float((a - b).abs().max()):.3e}"
+    finally:
+        ops.set_option("pp16", 1)
+        ops.set_precision("fp32")
