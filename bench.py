@@ -258,12 +258,10 @@ def main():
         for L in lanes:                      # every timed region starts at a GOP boundary
             L["t"] = 0
 
-    full_res = lambda pc, x0: (pc.kh == 3 and pc.stride == 1 and pc.segC == (64,) and pc.Cout == 64 and x0.H == H_pad and x0.W == W_pad)
-
     def timed(lanes, n):
         """Barrier + synchronize on both sides; every launch of the dominant conv shape inside is bracketed by HIP events on
         its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank], {residual operands: launches})"""
-        ops.PROFILE = {"match": full_res, "pairs": []}
+        ops.profile_begin(3, 1, 64, 64, H_pad, W_pad)        # HIP events around every launch of the dominant conv shape, recorded in the C library
         barrier()
         t0 = time.perf_counter()
         if len(lanes) == 1:
@@ -277,9 +275,9 @@ def main():
                 th.join()
         barrier()
         elapsed = time.perf_counter() - t0
-        prof, ops.PROFILE = ops.PROFILE, None
-        hist = {k: prof.get("nres", []).count(k) for k in (0, 1, 2)}
-        return max_over_ranks(elapsed), [a.elapsed_time(b) for a, b in prof["pairs"]], hist
+        durs, nres = ops.profile_end()
+        hist = {k: nres.count(k) for k in (0, 1, 2)}
+        return max_over_ranks(elapsed), durs, hist
 
     def pmc_traffic(section, hist):
         """HBM bytes per launch from the committed rocprofv3 --pmc passes (they cannot run in-process), weighted by THIS region's

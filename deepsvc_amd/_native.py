@@ -68,8 +68,12 @@ class ScanEw(Structure):
                 ("out", c_void_p), ("out_ld", c_int32), ("out_dtype", c_int32)]
 
 
+class ScanCall(Structure):
+    _fields_ = [("p", c_void_p * 6), ("i", c_int32 * 10), ("f", c_float * 2)]
+
+
 class _ScanU(ctypes.Union):
-    _fields_ = [("conv", ConvDesc), ("gc", ScanGc), ("eb", ScanEb), ("ew", ScanEw)]
+    _fields_ = [("conv", ConvDesc), ("gc", ScanGc), ("eb", ScanEb), ("ew", ScanEw), ("call", ScanCall)]
 
 
 class ScanOp(Structure):
@@ -77,6 +81,25 @@ class ScanOp(Structure):
 
 
 SCAN_CONV, SCAN_GC_QUANTIZE, SCAN_GC_DEQUANTIZE, SCAN_EB_PROCESS, SCAN_EB_DEQUANTIZE, SCAN_ELTWISE = 0, 1, 2, 3, 4, 5
+SCAN_WARP, SCAN_UPSAMPLE2X, SCAN_POOL2X2, SCAN_PIXEL_SHUFFLE, SCAN_NCHW_TO_NHWC, SCAN_NHWC_TO_NCHW, SCAN_SE_GATE = 6, 7, 8, 9, 10, 11, 12
+SCAN_UNION_MEMBER = {SCAN_CONV: "conv", SCAN_GC_QUANTIZE: "gc", SCAN_GC_DEQUANTIZE: "gc", SCAN_EB_PROCESS: "eb", SCAN_EB_DEQUANTIZE: "eb",
+                     SCAN_ELTWISE: "ew", SCAN_WARP: "call", SCAN_UPSAMPLE2X: "call", SCAN_POOL2X2: "call", SCAN_PIXEL_SHUFFLE: "call",
+                     SCAN_NCHW_TO_NHWC: "call", SCAN_NHWC_TO_NCHW: "call", SCAN_SE_GATE: "call"}
+
+
+def pointer_offsets(ctype, base=0):
+    """Byte offsets of every pointer-typed field inside a ctypes Structure / array (recursively)."""
+    out = []
+    if isinstance(ctype, type) and issubclass(ctype, ctypes.Array):
+        n, et = ctype._length_, ctype._type_
+        for k in range(n):
+            out += pointer_offsets(et, base + k * ctypes.sizeof(et))
+    elif isinstance(ctype, type) and issubclass(ctype, Structure):
+        for name, ft in ctype._fields_:
+            out += pointer_offsets(ft, base + getattr(ctype, name).offset)
+    elif ctype in (c_void_p, c_char_p):
+        out.append(base)
+    return out
 
 
 class Operand(Structure):
@@ -95,11 +118,14 @@ SIGNATURES = {
     "dsvc_device_count": (c_int, []),
     "dsvc_set_option": (c_int, [c_char_p, c_int]),
     "dsvc_get_counter": (c_int64, [c_char_p]),
+    "dsvc_profile_begin": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "dsvc_profile_end": (c_int64, [c_void_p, c_void_p, c_int64]),
     "dsvc_conv_packed_bytes": (c_int64, [c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32]),
     "dsvc_conv_pack_weights": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_int32), c_int32, c_int32, c_int32, c_void_p]),
     "dsvc_deconv5x5s2_to_conv3x3": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "dsvc_conv2d": (c_int, [c_void_p, POINTER(ConvDesc)]),
     "dsvc_entropy_scan_step": (c_int, [c_void_p, c_void_p, c_int32]),
+    "dsvc_pframe_segment_run": (c_int, [c_void_p, c_void_p, c_int32]),
     "dsvc_warp_bilinear_border": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                           c_int32, c_int32, c_int32, c_int32]),
     "dsvc_upsample2x_bilinear": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float]),

@@ -610,7 +610,61 @@ extern "C" int64_t dsvc_conv_packed_bytes(int32_t Cout, int32_t nseg, const int3
     return nch * kh * kw * Np * 64;
 }
 
+static int conv2d_impl(void* stream, const dsvc_conv_desc* d);
+
+// ---- per-launch timing of one conv SHAPE with HIP events on the launch stream (bench.py's roofline leg) --------------------
+// Works the same whether the launch comes from Python, from a recorded scan step or from a frame segment.
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int nres; };
+struct ProfState { bool active = false; int kh, stride, C, Cout, H, W; std::vector<ProfRec> recs; std::mutex mu; } g_prof;
+}
+extern "C" int dsvc_profile_begin(int32_t kh, int32_t stride, int32_t C, int32_t Cout, int32_t H, int32_t W) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.recs.clear();
+    g_prof.kh = kh; g_prof.stride = stride; g_prof.C = C; g_prof.Cout = Cout; g_prof.H = H; g_prof.W = W;
+    g_prof.active = true;
+    return DSVC_OK;
+}
+extern "C" int64_t dsvc_profile_end(float* ms_out, int32_t* nres_out, int64_t cap) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.active = false;
+    const int64_t n = (int64_t)g_prof.recs.size();
+    if (ms_out == nullptr) return n;                 // size query (records are kept)
+    for (int64_t i = 0; i < n && i < cap; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.recs[i].b) != hipSuccess || hipEventElapsedTime(&ms, g_prof.recs[i].a, g_prof.recs[i].b) != hipSuccess) {
+            dsvc_set_error("profile_end: event %lld not usable", (long long)i);
+            return DSVC_E_LAUNCH;
+        }
+        ms_out[i] = ms;
+        if (nres_out) nres_out[i] = g_prof.recs[i].nres;
+    }
+    for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.recs.clear();
+    return n;
+}
+
 extern "C" int dsvc_conv2d(void* stream, const dsvc_conv_desc* d) {
+    if (g_prof.active && d && d->nseg == 1 && d->kh == g_prof.kh && d->kw == g_prof.kh && d->stride == g_prof.stride && d->in[0].C == g_prof.C &&
+        d->Cout == g_prof.Cout && d->H == g_prof.H && d->W == g_prof.W && !d->s2d) {
+        ProfRec r{};
+        if (hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) {
+            r.nres = (d->res1 ? 1 : 0) + (d->res2 ? 1 : 0);
+            (void)hipEventRecord(r.a, (hipStream_t)stream);
+            const int rc = conv2d_impl(stream, d);
+            (void)hipEventRecord(r.b, (hipStream_t)stream);
+            std::lock_guard<std::mutex> lk(g_prof.mu);
+            g_prof.recs.push_back(r);
+            return rc;
+        }
+    }
+    return conv2d_impl(stream, d);
+}
+
+static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     DSVC_REQUIRE(d != nullptr, "conv2d: null descriptor");
     DSVC_REQUIRE(d->nseg >= 1 && d->nseg <= 3, "conv2d: nseg=%d out of 1..3", d->nseg);
     DSVC_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, "conv2d: bad shape B=%d H=%d W=%d Cout=%d", d->B, d->H, d->W, d->Cout);

@@ -188,6 +188,42 @@ extern "C" int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int
                 rc = dsvc_eltwise(stream, w.op, w.n_pix, w.C, opt(w.a), opt(w.b), opt(w.c), opt(w.d), opt(w.e), w.out, w.out_ld, w.out_dtype);
                 break;
             }
+            case DSVC_SCAN_WARP: {
+                const dsvc_scan_call& c = o.u.call;
+                rc = dsvc_warp_bilinear_border(stream, c.p[0], c.i[0], c.i[1], (const float*)c.p[1], c.i[2], (void*)c.p[2], c.i[3], c.i[4], c.i[5], c.i[6], c.i[7], c.i[8]);
+                break;
+            }
+            case DSVC_SCAN_UPSAMPLE2X: {
+                const dsvc_scan_call& c = o.u.call;
+                rc = dsvc_upsample2x_bilinear(stream, (const float*)c.p[0], c.i[0], (float*)c.p[1], c.i[1], c.i[2], c.i[3], c.i[4], c.i[5], c.f[0]);
+                break;
+            }
+            case DSVC_SCAN_POOL2X2: {
+                const dsvc_scan_call& c = o.u.call;
+                rc = dsvc_pool2x2(stream, c.i[0], c.p[0], c.i[1], (void*)c.p[1], c.i[2], c.i[3], c.i[4], c.i[5], c.i[6], c.i[7]);
+                break;
+            }
+            case DSVC_SCAN_PIXEL_SHUFFLE: {
+                const dsvc_scan_call& c = o.u.call;
+                rc = dsvc_pixel_shuffle_nchw(stream, (const float*)c.p[0], (void*)c.p[1], c.i[0], c.i[1], c.i[2], c.i[3], c.i[4], c.i[5], c.i[6]);
+                break;
+            }
+            case DSVC_SCAN_NCHW_TO_NHWC: {
+                const dsvc_scan_call& c = o.u.call;
+                rc = dsvc_nchw_to_nhwc(stream, (const float*)c.p[0], (void*)c.p[1], c.i[0], c.i[1], c.i[2], c.i[3], c.i[4], c.i[5]);
+                break;
+            }
+            case DSVC_SCAN_NHWC_TO_NCHW: {
+                const dsvc_scan_call& c = o.u.call;
+                rc = dsvc_nhwc_to_nchw(stream, c.p[0], c.i[0], c.i[1], (float*)c.p[1], c.i[2], c.i[3], c.i[4], c.i[5]);
+                break;
+            }
+            case DSVC_SCAN_SE_GATE: {
+                const dsvc_scan_call& c = o.u.call;
+                rc = dsvc_se_gate(stream, c.p[0], c.i[0], c.i[1], c.i[2], c.i[3], c.i[4], c.i[5], (const float*)c.p[1], (const float*)c.p[2], c.i[6],
+                                  (float*)c.p[3], (float*)c.p[4]);
+                break;
+            }
             default:
                 dsvc_set_error("entropy_scan_step: op %d has unknown kind %d", i, o.kind);
                 return DSVC_E_ARG;
@@ -200,4 +236,8 @@ extern "C" int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int
         }
     }
     return DSVC_OK;
+}
+
+extern "C" int dsvc_pframe_segment_run(void* stream, const dsvc_scan_op* ops, int32_t n_ops) {
+    return dsvc_entropy_scan_step(stream, ops, n_ops);       // same interpreter: a frame segment is a longer op list
 }

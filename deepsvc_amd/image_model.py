@@ -403,6 +403,9 @@ class ChannelSplitICIP2020ResB(nn.Module):
             the launches;
           * once captured (capture_scan_graphs), the same sequence is replayed as a HIP graph: the CPU cost per segment drops
             from ~30 us per launch to one graph launch."""
+        if ops._rec() is not None:            # inside a recorded frame segment: the launches become part of THAT program
+            fn()
+            return
         valid = plan.epoch == self._epoch_ref()[0]
         g = plan.graphs.get(key) if ops.USE_GRAPHS[0] and valid else None
         if g is not None:
@@ -509,16 +512,20 @@ class ChannelSplitICIP2020ResB(nn.Module):
             self._group_params(ws, group)
             ops.run_parallel([(lambda i=i: code_slice(i)) for i in group])
 
-    def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None, defer=False):
-        """-> ({"strings", "shape"} dict (lazy PendingStrings when defer=True), x_hat Act or None)."""
-        gc, eb = self.gaussian_conditional, self.entropy_bottleneck
+    def enc_gpu(self, segments, ws=None):
+        """GPU half of compress(): analysis transform into the scan workspace + the whole encoder scan (no host interaction)."""
         x0 = segments[0]
-        ws = self._plan(x0.B, x0.H // 16, x0.W // 16, x0.device)
+        ws = ws or self._plan(x0.B, x0.H // 16, x0.W // 16, x0.device)
         self._g_a(segments, ws.y)
         self._step(ws, "enc", lambda: self._enc_scan(ws))
+        return ws
+
+    def enc_finish(self, ws, defer=False):
+        """Host half: the symbol / index planes leave the device through one async copy into pinned memory; the host range coder
+        runs on a worker thread behind the copy's event, so the caller can keep queuing GPU work (synthesis transform, MC, ...).
+        -> {"strings", "shape"} dict (a lazy PendingStrings when defer=True)."""
+        gc, eb = self.gaussian_conditional, self.entropy_bottleneck
         nz, ny = ws.nz, ws.ny
-        # Symbols leave the device through one async copy into pinned memory; the host range coder runs on a worker
-        # thread behind the copy's event, so the caller can keep queuing GPU work (synthesis transform, MC, ...).
         host = torch.empty(ws.staging.numel(), dtype=torch.int32, pin_memory=True)
         host.copy_(ws.staging, non_blocking=True)
         done = torch.cuda.Event()
@@ -537,8 +544,14 @@ class ChannelSplitICIP2020ResB(nn.Module):
         self.__dict__.setdefault("_pending_futures", []).append(future)
         del self.__dict__["_pending_futures"][:-4]      # keep only the most recent few (older ones have long finished)
         pending = PendingStrings(future)
+        return pending if defer else pending.result()
+
+    def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None, defer=False):
+        """-> ({"strings", "shape"} dict (lazy PendingStrings when defer=True), x_hat Act or None)."""
+        ws = self.enc_gpu(segments)
+        pending = self.enc_finish(ws, defer)
         x_hat = self._g_s(ws.y_hat, None, x_hat_dtype) if want_x_hat else None
-        return (pending if defer else pending.result()), x_hat
+        return pending, x_hat
 
     def _dec_nets(self, ws, group):
         """parameter nets + index planes of one dependency level (slices of `group` share their support)."""
@@ -559,6 +572,11 @@ class ChannelSplitICIP2020ResB(nn.Module):
         ops.run_parallel([(lambda j=j, i=i: one(j, i)) for j, i in enumerate(group)])
 
     def run_decompress(self, strings, shape, device, x_hat_out=None, x_hat_dtype=None):
+        ws = self.dec_chain(strings, shape, device)
+        return self._g_s(ws.y_hat, x_hat_out, x_hat_dtype)
+
+    def dec_chain(self, strings, shape, device):
+        """strings -> y_hat in the scan workspace: host range decoder and scan kernels, level by level (one sync point per level)."""
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck
         h4, w4 = int(shape[0]), int(shape[1])
         B = len(strings[1])
@@ -581,7 +599,7 @@ class ChannelSplitICIP2020ResB(nn.Module):
             dec.decode_stream(ws.idx_host.numpy()[:m], tables, out=ws.sym_host.numpy()[:m])
             ws.sym_dev[:m].copy_(ws.sym_host[:m], non_blocking=True)
             self._step(ws, f"dec{k + 1}", steps[f"dec{k + 1}"])
-        return self._g_s(ws.y_hat, x_hat_out, x_hat_dtype)
+        return ws
 
     # ------------------------------------------------------------------------------------------
     # reference-style API (NCHW tensors)

@@ -225,7 +225,10 @@ class ME_Spynet(nn.Module):
             pyr1.append(ops.pool2x2(pyr1[-1], "avg"))
             pyr2.append(ops.pool2x2(pyr2[-1], "avg"))
         top = pyr2[-1]
-        flow = Act(torch.zeros((top.B, top.H // 2, top.W // 2, 2), dtype=torch.float32, device=top.device))
+        zkey = (top.B, top.H // 2, top.W // 2, str(top.device))
+        flow = self.__dict__.setdefault("_zero_flow", {}).get(zkey)       # the all-zero coarsest flow: allocated once, only ever read
+        if flow is None:
+            flow = self.__dict__["_zero_flow"][zkey] = Act(torch.zeros((top.B, top.H // 2, top.W // 2, 2), dtype=torch.float32, device=top.device))
         for level in range(self.L):
             up = ops.upsample2x(flow, 2.0)
             k = self.L - 1 - level

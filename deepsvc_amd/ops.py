@@ -87,6 +87,7 @@ class ScanRecorder:
 
     def __init__(self):
         self.ops, self.keep, self.poisoned = [], [], None
+        self.temps = []           # buffers handed out by new_act / scratch while recording: a FrameProgram packs them into one arena
 
     def __enter__(self):
         self.prev = getattr(_recording, "cur", None)
@@ -126,6 +127,137 @@ class ScanProgram:
 
     def run(self):
         N.check(N.lib().dsvc_entropy_scan_step(_stream(), ctypes.addressof(self.arr), self.n), "entropy_scan_step")
+
+
+class FrameProgram:
+    """A frozen recording of one host-synchronisation-free SEGMENT of a P-frame (include/dsvc.h: dsvc_pframe_segment_run).
+
+    Pointers inside the recorded ops fall into three classes, found by address range:
+      * externals -- the caller's frame tensors (ref / cur / feature / sm_fea ...) and the segment's FRESH outputs (tensors handed
+        back to the caller, newly allocated on every run like the reference's return values): patched into the op array per run;
+      * temporaries -- everything new_act() handed out while recording: packed by lifetime (first .. last op that touches them) into
+        ONE arena owned by the program, patched once;
+      * everything else (packed weights, bias, scan workspaces, persistent outputs that a later segment reads): left as recorded and
+        kept alive by the program.
+    run(externals) = patch ~10-20 pointers + one C call that issues the segment's launches back to back."""
+
+    ALIGN = 512
+
+    def __init__(self, rec, externals, fresh, persistent):
+        """externals: [Act | tensor] inputs in binding order; fresh: [Act] outputs reallocated per run; persistent: [Act] outputs kept."""
+        assert rec.poisoned is None
+        self.n = len(rec.ops)
+        self.arr = (N.ScanOp * max(self.n, 1))(*rec.ops)
+        buf_of = lambda e: e.buf if isinstance(e, Act) else e
+        rng = lambda t: (t.data_ptr(), t.data_ptr() + t.numel() * t.element_size())
+        ext = [buf_of(e) for e in externals] + [a.buf for a in fresh]
+        self.n_inputs, self.fresh_meta = len(externals), [(tuple(a.buf.shape), a.buf.dtype, a.buf.device, a.c0, a.C) for a in fresh]
+        keep_ids = {id(a.buf) for a in persistent} | {id(t) for t in ext}
+        temps = [t for t in {id(t): t for t in rec.temps}.values() if id(t) not in keep_ids]
+        table = sorted([(rng(t) + ("ext", i)) for i, t in enumerate(ext)] + [(rng(t) + ("tmp", i)) for i, t in enumerate(temps)])
+        starts = [r[0] for r in table]
+        import bisect
+
+        def owner(v):
+            k = bisect.bisect_right(starts, v) - 1
+            if k >= 0 and table[k][0] <= v < table[k][1]:
+                return table[k]
+            return None
+
+        base = ctypes.addressof(self.arr)
+        step, uoff = ctypes.sizeof(N.ScanOp), N.ScanOp.u.offset
+        offs = {m: N.pointer_offsets(dict(N._ScanU._fields_)[m]) for m in set(N.SCAN_UNION_MEMBER.values())}
+        first, last = [None] * len(temps), [None] * len(temps)
+        ext_rel, tmp_rel = [], []                    # (field address, slot, delta)
+        for i in range(self.n):
+            for o in offs[N.SCAN_UNION_MEMBER[self.arr[i].kind]]:
+                addr = base + i * step + uoff + o
+                v = ctypes.c_uint64.from_address(addr).value
+                if not v:
+                    continue
+                own = owner(v)
+                if own is None:
+                    continue
+                lo, _, kind, slot = own
+                if kind == "ext":
+                    ext_rel.append((ctypes.c_uint64.from_address(addr), slot, v - lo))
+                else:
+                    tmp_rel.append((addr, slot, v - lo))
+                    first[slot] = i if first[slot] is None else first[slot]
+                    last[slot] = i
+        # ---- pack the temporaries into one arena by lifetime (greedy first fit over freed blocks) ----
+        order = sorted((k for k in range(len(temps)) if first[k] is not None), key=lambda k: first[k])
+        size = lambda k: -(-(temps[k].numel() * temps[k].element_size()) // self.ALIGN) * self.ALIGN
+        free, live, offset, top = [], [], {}, 0       # free: [(off, size)], live: [(last, off, size)]
+        for k in order:
+            for item in [x for x in live if x[0] < first[k]]:
+                live.remove(item)
+                free.append((item[1], item[2]))
+            free.sort()
+            merged = []
+            for off, sz in free:                       # coalesce neighbours
+                if merged and merged[-1][0] + merged[-1][1] == off:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                else:
+                    merged.append((off, sz))
+            free = merged
+            need, pick = size(k), None
+            for j, (off, sz) in enumerate(free):
+                if sz >= need and (pick is None or sz < free[pick][1]):
+                    pick = j
+            if pick is not None:
+                off, sz = free.pop(pick)
+                if sz > need:
+                    free.append((off + need, sz - need))
+                offset[k] = off
+            else:
+                if free and free[-1][0] + free[-1][1] == top:      # grow the last free block instead of leaving a hole
+                    off, sz = free.pop()
+                    offset[k], top = off, off + need
+                else:
+                    offset[k], top = top, top + need
+            live.append((last[k], offset[k], need))
+        dev = temps[0].device if temps else (ext[0].device if ext else None)
+        self.arena = torch.empty(max(top, self.ALIGN), dtype=torch.uint8, device=dev) if dev is not None else None
+        self.arena_bytes, self.temp_bytes = top, sum(size(k) for k in order)
+        abase = self.arena.data_ptr() if self.arena is not None else 0
+        for addr, slot, delta in tmp_rel:
+            ctypes.c_uint64.from_address(addr).value = abase + offset[slot] + delta
+        self.ext_rel = ext_rel
+        tmp_ids = {id(t) for t in temps}
+        self.keep = [k for k in rec.keep if not (isinstance(k, torch.Tensor) and (id(k) in tmp_ids or id(k) in {id(t) for t in ext}))]
+        self.persistent = list(persistent)
+
+    def run(self, externals):
+        """-> (fresh output Acts, persistent output Acts)"""
+        assert len(externals) == self.n_inputs
+        bases = [(e.buf if isinstance(e, Act) else e).data_ptr() for e in externals]
+        fresh = []
+        for shape, dtype, dev, c0, C in self.fresh_meta:
+            a = Act(torch.empty(shape, dtype=dtype, device=dev), c0, C)
+            fresh.append(a)
+            bases.append(a.buf.data_ptr())
+        for cell, slot, delta in self.ext_rel:
+            cell.value = bases[slot] + delta
+        N.check(N.lib().dsvc_pframe_segment_run(_stream(), ctypes.addressof(self.arr), self.n), "pframe_segment_run")
+        return fresh, self.persistent
+
+
+FRAME_PROGRAMS = [_os.environ.get("DSVC_NO_FRAME_PROGRAMS", "") == ""]
+
+
+def run_segment(cache, key, externals, fn, n_fresh=0):
+    """Run one frame segment: fn(*externals) -> (fresh outputs [Act...], persistent outputs [Act...]).  First call: issued launch by
+    launch while recorded; afterwards one FrameProgram.run.  A segment holding an op without a scan-op form stays eager."""
+    prog = cache.get(key) if (FRAME_PROGRAMS[0] and cache is not None) else False
+    if prog is False or _rec() is not None:
+        return fn(*externals)
+    if prog is None:
+        with ScanRecorder() as rec:
+            fresh, persistent = fn(*externals)
+        cache[key] = False if rec.poisoned is not None else FrameProgram(rec, externals, fresh, persistent)
+        return fresh, persistent
+    return prog.run(externals)
 
 
 def set_option(key, value):
@@ -207,8 +339,8 @@ class Act:
         """Logical NCHW fp32 view/copy for the reference-style API."""
         if self.dtype == torch.float32:
             return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
-        poison_recording("nhwc_to_nchw")          # not a scan-step op
-        out = torch.empty((self.B, self.C, self.H, self.W), dtype=torch.float32, device=self.device)
+        out = scratch((self.B, self.C, self.H, self.W), torch.float32, self.device)
+        _rec_call(N.SCAN_NHWC_TO_NCHW, [self.ptr, out.data_ptr()], [self.ld, self.code, self.B, self.C, self.H, self.W], keep=[self.buf, out])
         N.check(N.lib().dsvc_nhwc_to_nchw(_stream(), self.ptr, self.ld, self.code, out.data_ptr(),
                                           self.B, self.C, self.H, self.W), "nhwc_to_nchw")
         return out
@@ -220,7 +352,31 @@ def new_act(B, H, W, C, dtype=None, device=None, ld=None):
     r = getattr(_recording, "cur", None)
     if r is not None:            # a temporary of a recorded scan step: replays write to this address, so it must stay allocated
         r.keep.append(a.buf)
+        r.temps.append(a.buf)
     return a
+
+
+def scratch(shape, dtype, device):
+    """A plain temporary tensor (workspace / small result) that a recording knows about."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    r = getattr(_recording, "cur", None)
+    if r is not None:
+        r.keep.append(t)
+        r.temps.append(t)
+    return t
+
+
+def _rec_call(kind, ptrs, ints, floats=(), keep=()):
+    r = _rec()
+    if r is not None:
+        c = N.ScanCall()
+        for k, v in enumerate(ptrs):
+            c.p[k] = v
+        for k, v in enumerate(ints):
+            c.i[k] = int(v)
+        for k, v in enumerate(floats):
+            c.f[k] = float(v)
+        r.add(kind, "call", c, list(keep))
 
 
 def to_act(x, dtype=None):
@@ -233,10 +389,12 @@ def to_act(x, dtype=None):
     xp = x.permute(0, 2, 3, 1)
     if x.dtype == want and xp.is_contiguous():
         return Act(xp)
-    poison_recording("nchw_to_nhwc")          # not a scan-step op
     B, C, H, W = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        poison_recording("nchw_to_nhwc of a tensor that needs a torch copy first")
     src = x.to(torch.float32).contiguous() if (x.dtype != torch.float32 or not x.is_contiguous()) else x
     out = new_act(B, H, W, C, want, x.device)
+    _rec_call(N.SCAN_NCHW_TO_NHWC, [src.data_ptr(), out.ptr], [out.ld, out.code, B, C, H, W], keep=[src, out.buf])
     N.check(N.lib().dsvc_nchw_to_nhwc(_stream(), src.data_ptr(), out.ptr, out.ld, out.code, B, C, H, W), "nchw_to_nhwc")
     return out
 
@@ -336,9 +494,18 @@ def deconv_as_conv_weights(w_iohw, bias):
     return wo, bo
 
 
-# Optional per-launch timing of selected conv launches with HIP events recorded on the launch stream
-# (bench.py's roofline leg): {"match": fn(pc, x0) -> bool, "pairs": [(start_event, end_event), ...]}
-PROFILE = None
+def profile_begin(kh, stride, C, Cout, H, W):
+    """Arm per-launch HIP-event timing of one conv shape inside the C library (include/dsvc.h: dsvc_profile_begin)."""
+    N.check(N.lib().dsvc_profile_begin(kh, stride, C, Cout, H, W), "profile_begin")
+
+
+def profile_end():
+    """-> ([ms per matching launch], [residual operands per launch])"""
+    L = N.lib()
+    n = N.check(L.dsvc_profile_end(None, None, 0), "profile_end(count)")
+    ms, nres = (ctypes.c_float * max(n, 1))(), (ctypes.c_int32 * max(n, 1))()
+    N.check(L.dsvc_profile_end(ms, nres, n), "profile_end")
+    return list(ms)[:n], list(nres)[:n]
 
 
 def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.01, res1=None, gate=None, res2=None,
@@ -400,15 +567,6 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
     r = _rec()
     if r is not None:
         r.add(N.SCAN_CONV, "conv", d, [pc, out.buf, gate, post] + [a.buf for a in inputs] + [x.buf for x in (res1, res2) if x is not None])
-    prof = PROFILE
-    if prof is not None and prof["match"](pc, x0):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
-        e1.record()
-        prof["pairs"].append((e0, e1))
-        prof.setdefault("nres", []).append(int(res1 is not None) + int(res2 is not None))
-        return out
     N.check(N.lib().dsvc_conv2d(_stream(), byref(d)), "conv2d")
     return out
 
@@ -464,37 +622,39 @@ def items_ok(acts):
 # resampling / layout / pointwise
 # --------------------------------------------------------------------------------------------
 def warp(x, flow, out=None):
-    poison_recording("warp")          # not a scan-step op
     assert flow.dtype == torch.float32 and flow.C == 2
     out = out or new_act(x.B, x.H, x.W, x.C, x.dtype, x.device)
+    _rec_call(N.SCAN_WARP, [x.ptr, flow.ptr, out.ptr], [x.ld, x.code, flow.ld, out.ld, out.code, x.B, x.H, x.W, x.C], keep=[x.buf, flow.buf, out.buf])
     N.check(N.lib().dsvc_warp_bilinear_border(_stream(), x.ptr, x.ld, x.code, flow.ptr, flow.ld, out.ptr, out.ld, out.code,
                                               x.B, x.H, x.W, x.C), "warp")
     return out
 
 
 def upsample2x(x, scale=1.0, out=None):
-    poison_recording("upsample2x")          # not a scan-step op
     assert x.dtype == torch.float32
     out = out or new_act(x.B, 2 * x.H, 2 * x.W, x.C, torch.float32, x.device)
+    _rec_call(N.SCAN_UPSAMPLE2X, [x.ptr, out.ptr], [x.ld, out.ld, x.B, x.H, x.W, x.C], [scale], keep=[x.buf, out.buf])
     N.check(N.lib().dsvc_upsample2x_bilinear(_stream(), x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, x.C, float(scale)), "upsample2x")
     return out
 
 
 def pool2x2(x, mode, out=None):
-    poison_recording("pool2x2")          # not a scan-step op
     out = out or new_act(x.B, x.H // 2, x.W // 2, x.C, x.dtype, x.device)
     assert out.dtype == x.dtype
+    _rec_call(N.SCAN_POOL2X2, [x.ptr, out.ptr], [0 if mode == "avg" else 1, x.ld, out.ld, x.code, x.B, x.H, x.W, x.C], keep=[x.buf, out.buf])
     N.check(N.lib().dsvc_pool2x2(_stream(), 0 if mode == "avg" else 1, x.ptr, x.ld, out.ptr, out.ld, x.code, x.B, x.H, x.W, x.C), "pool2x2")
     return out
 
 
 def pixel_shuffle_nchw(x_nchw, r, out=None, dtype=None):
-    poison_recording("pixel_shuffle_nchw")          # not a scan-step op
     _require_gpu(x_nchw)
+    if x_nchw.dtype != torch.float32 or not x_nchw.is_contiguous():
+        poison_recording("pixel_shuffle_nchw of a tensor that needs a torch copy first")
     x = x_nchw.to(torch.float32).contiguous()
     B, C, H, W = x.shape
     co = C // (r * r)
     out = out or new_act(B, H * r, W * r, co, dtype, x.device)
+    _rec_call(N.SCAN_PIXEL_SHUFFLE, [x.data_ptr(), out.ptr], [out.ld, out.code, B, co, H, W, r], keep=[x, out.buf])
     N.check(N.lib().dsvc_pixel_shuffle_nchw(_stream(), x.data_ptr(), out.ptr, out.ld, out.code, B, co, H, W, r), "pixel_shuffle")
     return out
 
@@ -521,10 +681,11 @@ def eltwise(op, a, b=None, c=None, d=None, e=None, out=None, out_dtype=None):
 
 def se_gate(x, w1, w2):
     """SELayer gate [B, C] fp32 for activation x (w1 [C/r, C], w2 [C, C/r] device fp32)."""
-    poison_recording("se_gate")          # not a scan-step op
     L = N.lib()
-    ws = torch.empty(L.dsvc_se_workspace_floats(x.B, x.C), dtype=torch.float32, device=x.device)
-    gate = torch.empty((x.B, x.C), dtype=torch.float32, device=x.device)
+    ws = scratch((L.dsvc_se_workspace_floats(x.B, x.C),), torch.float32, x.device)
+    gate = scratch((x.B, x.C), torch.float32, x.device)
+    _rec_call(N.SCAN_SE_GATE, [x.ptr, w1.data_ptr(), w2.data_ptr(), ws.data_ptr(), gate.data_ptr()], [x.ld, x.code, x.B, x.H, x.W, x.C, w1.shape[0]],
+              keep=[x.buf, w1, w2, ws, gate])
     N.check(L.dsvc_se_gate(_stream(), x.ptr, x.ld, x.code, x.B, x.H, x.W, x.C, w1.data_ptr(), w2.data_ptr(), w1.shape[0],
                            ws.data_ptr(), gate.data_ptr()), "se_gate")
     return gate

@@ -143,19 +143,60 @@ class DeepSVC(nn.Module):
     # ------------------------------------------------------------------------------------------
     # real bitstream path
     # ------------------------------------------------------------------------------------------
+    # Frame segments (include/dsvc.h: dsvc_pframe_segment_run): a P-frame is five host-synchronisation-free launch sequences -- E1
+    # (motion estimation, motion analysis, encoder scan), E2 (motion synthesis, prediction, feature extraction, residual analysis,
+    # encoder scan), D1 (motion synthesis, prediction, feature extraction), DR (residual synthesis, on the side stream) and D2
+    # (residual refinement, enhancement, clamps) -- with the host range coder between them.  Each is recorded on its first execution
+    # and replayed by ONE C call afterwards (ops.run_segment / ops.FrameProgram); every tensor that crosses a segment boundary is
+    # passed in as an external, so a segment never depends on where its inputs were produced.
+    def _segments(self, ref, *others):
+        """(program cache, key prefix) for this call, or (None, None) when the call must run launch by launch (parity tests tap
+        intermediate tensors).  Programs hold pointers to packed weights: any weight edit drops them."""
+        if self.__dict__.get("debug_taps") is not None or not ops.FRAME_PROGRAMS[0]:
+            return None, None
+        ps = self.__dict__.get("_fp_params")
+        if ps is None:
+            ps = self.__dict__["_fp_params"] = list(self.parameters())
+        fp = sum(p._version for p in ps)
+        cache = self.__dict__.setdefault("_frame_programs", {})
+        if self.__dict__.get("_fp_seen") != fp:
+            cache.clear()
+            self.__dict__["_fp_seen"] = fp
+        sig = lambda t: (tuple(t.buf.shape), t.c0, t.C, t.code) if isinstance(t, Act) else \
+            (None if t is None else (tuple(t.shape), str(t.dtype), t.is_contiguous()))
+        return cache, (str(ref.device), ops.RT.mode, ops.RT.compute, sig(ref)) + tuple(sig(t) for t in others)
+
     @torch.no_grad()
     def compress(self, ref_frame, curr_frame, sm_fea, feature=None):
         """video_model.py:137-151 -> (mv_out_enc, res_out_enc), each {"strings": [[y],[z...]], "shape": (h,w)}."""
         ref, cur = to_act(ref_frame), to_act(curr_frame)
         self._maybe_capture_graphs(ref)
-        mv_est = self.opticFlow.run(cur, ref)
+        feat = self._feature_in(feature)
+        cache, key = self._segments(ref, cur, sm_fea, feat)
+        ws_mv = self.mv_codec._plan(ref.B, ref.H // 16, ref.W // 16, ref.device)
+        ws_res = self.res_codec._plan(ref.B, ref.H // 16, ref.W // 16, ref.device)
+        opt = [] if feat is None else [feat]
+
+        def e1(ref, cur):
+            mv_est = self.opticFlow.run(cur, ref)
+            self.mv_codec.enc_gpu([cur, mv_est, ref], ws_mv)
+            return [], []
+
+        def e2(ref, cur, sm, *f):
+            # (the reference entropy-decodes its own mv stream here, video_model.py:141: y_hat is already on the device)
+            mv_coarse = self.mv_codec._g_s(ws_mv.y_hat, None, F32)
+            _, _, predict = self._predict(ref, mv_coarse, sm, f[0] if f else None)
+            predict_fea = self.FeatureExtractor.run(predict)
+            cur_fea = self.FeatureExtractor.run(cur)
+            res = ops.eltwise(N.EW_SUB, cur_fea, predict_fea)
+            self.res_codec.enc_gpu([ref, res, predict], ws_res)
+            return [], []
+
+        ops.run_segment(cache, ("E1", key), [ref, cur], e1)
         # the mv streams are range-coded on a worker thread while the GPU runs prediction + the residual analysis
-        mv_pending, mv_coarse = self.mv_codec.run_compress([cur, mv_est, ref], want_x_hat=True, x_hat_dtype=F32, defer=True)
-        _, _, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
-        predict_fea = self.FeatureExtractor.run(predict)
-        cur_fea = self.FeatureExtractor.run(cur)
-        res = ops.eltwise(N.EW_SUB, cur_fea, predict_fea)
-        res_pending, _ = self.res_codec.run_compress([ref, res, predict], defer=True)
+        mv_pending = self.mv_codec.enc_finish(ws_mv, defer=True)
+        ops.run_segment(cache, ("E2", key), [ref, cur, sm_fea] + opt, e2)
+        res_pending = self.res_codec.enc_finish(ws_res, defer=True)
         # both are dicts that join their coder thread on first access: a caller that forwards them to decompress()
         # without looking inside overlaps the residual range coding with the decoder's motion path
         return mv_pending, res_pending
@@ -166,6 +207,10 @@ class DeepSVC(nn.Module):
         ref = to_act(ref_frame)
         dev = ref.device
         self._maybe_capture_graphs(ref)
+        feat = self._feature_in(feature)
+        cache, key = self._segments(ref, sm_fea, feat)
+        opt = [] if feat is None else [feat]
+        taps = self.__dict__.get("debug_taps")
         # The residual codec's decode chain (host range decoder + tiny scan kernels, 5 sync points) does not depend on
         # the motion path until reconstruction: it runs on a worker thread / side stream so its idle gaps overlap the
         # motion decode chain and the MC / feature-extraction kernels of the main stream.
@@ -177,26 +222,38 @@ class DeepSVC(nn.Module):
         def decode_residual():
             strings, shape = res_out_enc["strings"], res_out_enc["shape"]   # joins the encoder thread if still coding
             with torch.cuda.stream(side):
-                out = self.res_codec.run_decompress(strings, shape, dev)
+                ws = self.res_codec.dec_chain(strings, shape, dev)
+                _, (out,) = ops.run_segment(cache, ("DR", key), [], lambda: ([], [self.res_codec._g_s(ws.y_hat)]))
                 res_done.record(side)
             return out
 
         res_future = _DECODE_POOL.submit(decode_residual)
-        mv_coarse = self.mv_codec.run_decompress(mv_out_enc["strings"], mv_out_enc["shape"], dev, x_hat_dtype=F32)
-        warped, warp_fea, predict = self._predict(ref, mv_coarse, sm_fea, self._feature_in(feature))
-        predict_fea = self.FeatureExtractor.run(predict)
+        ws_mv = self.mv_codec.dec_chain(mv_out_enc["strings"], mv_out_enc["shape"], dev)
+
+        def d1(ref, sm, *f):
+            mv_coarse = self.mv_codec._g_s(ws_mv.y_hat, None, F32)
+            warped, warp_fea, predict = self._predict(ref, mv_coarse, sm, f[0] if f else None)
+            predict_fea = self.FeatureExtractor.run(predict)
+            if taps is not None:
+                taps.update(mv_coarse=mv_coarse.nchw().float().clone())
+            return [], [warped, warp_fea, predict, predict_fea]
+
+        def d2(ref, warped, warp_fea, predict, predict_fea, res_coarse):
+            fea, recon = self._reconstruct(ref, predict_fea, res_coarse, warp_fea)
+            if taps is not None:      # parity tests look at the tensors in front of the clamps (a dict set by the caller; never set in production)
+                taps.update(recon=recon.nchw().clone(), warped=warped.nchw().clone(), predict=predict.nchw().clone(),
+                            warp_fea=warp_fea.nchw().float().clone(), predict_fea=predict_fea.nchw().float().clone(),
+                            res_coarse=res_coarse.nchw().float().clone())
+            clamp = lambda a: ops.eltwise(N.EW_CLAMP01, a)
+            return [fea, clamp(recon), clamp(warped), clamp(predict)], []
+
+        _, (warped, warp_fea, predict, predict_fea) = ops.run_segment(cache, ("D1", key), [ref, sm_fea] + opt, d1)
         res_coarse = res_future.result()
         main.wait_event(res_done)
         res_coarse.buf.record_stream(main)
-        feat, recon = self._reconstruct(ref, predict_fea, res_coarse, warp_fea)
-        taps = self.__dict__.get("debug_taps")
-        if taps is not None:      # parity tests look at the tensors in front of the clamps (a dict set by the caller; never set in production)
-            taps.update(recon=recon.nchw().clone(), warped=warped.nchw().clone(), predict=predict.nchw().clone(),
-                        warp_fea=warp_fea.nchw().float().clone(), predict_fea=predict_fea.nchw().float().clone(),
-                        res_coarse=res_coarse.nchw().float().clone(), mv_coarse=mv_coarse.nchw().float().clone())
-        clamp = lambda a: ops.eltwise(N.EW_CLAMP01, a).nchw()
+        (fea, recon_c, warped_c, predict_c), _ = ops.run_segment(cache, ("D2", key), [ref, warped, warp_fea, predict, predict_fea, res_coarse], d2)
         # `feature` is only ever handed back to the next frame: return it zero-copy in its storage layout/dtype
-        return feat.nchw_view(), clamp(recon), clamp(warped), clamp(predict)
+        return fea.nchw_view(), recon_c.nchw(), warped_c.nchw(), predict_c.nchw()
 
     # ------------------------------------------------------------------------------------------
     # bookkeeping (same contracts as the reference)

@@ -64,6 +64,13 @@ int dsvc_set_option(const char* key, int value);
  * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1".  Tests use it to prove that the
  * large-image kernels ran inside a frame that is checked against the reference.  Returns DSVC_E_ARG for an unknown key. */
 int64_t dsvc_get_counter(const char* key);
+/* Diagnostic: time every dsvc_conv2d launch of ONE shape (single-segment k x k conv, `stride`, C -> Cout channels on an H x W input) with
+ * HIP events recorded on the launch stream, wherever the launch comes from (direct call, scan step, frame segment).
+ * dsvc_profile_begin arms it (dropping earlier records); dsvc_profile_end disarms it, waits for the events and writes up to `cap`
+ * durations in ms (and the number of residual operands of each launch); returns the number of records (ms_out == NULL: count only,
+ * records kept).  Process-wide; used by bench.py's roofline leg. */
+int dsvc_profile_begin(int32_t kh, int32_t stride, int32_t C, int32_t Cout, int32_t H, int32_t W);
+int64_t dsvc_profile_end(float* ms_out, int32_t* nres_out, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution family (one MFMA implicit-GEMM kernel, fused epilogue).
@@ -274,12 +281,36 @@ typedef struct dsvc_scan_ew {
     dsvc_operand a, b, c, d, e;      /* an absent operand has ptr == NULL */
     void* out; int32_t out_ld, out_dtype;
 } dsvc_scan_ew;
+/* op kinds beyond the entropy scan: what a whole P-frame segment needs besides convs (frame level, below) */
+#define DSVC_SCAN_WARP 6            /* u.call: dsvc_warp_bilinear_border  p = {in, flow, out}     i = {in_ld, in_dtype, flow_ld, out_ld, out_dtype, B, H, W, C} */
+#define DSVC_SCAN_UPSAMPLE2X 7      /* u.call: dsvc_upsample2x_bilinear   p = {in, out}           i = {in_ld, out_ld, B, H, W, C}   f = {scale} */
+#define DSVC_SCAN_POOL2X2 8         /* u.call: dsvc_pool2x2               p = {in, out}           i = {mode, in_ld, out_ld, dtype, B, H, W, C} */
+#define DSVC_SCAN_PIXEL_SHUFFLE 9   /* u.call: dsvc_pixel_shuffle_nchw    p = {in_nchw, out}      i = {out_ld, out_dtype, B, Cout, Hin, Win, r} */
+#define DSVC_SCAN_NCHW_TO_NHWC 10   /* u.call: dsvc_nchw_to_nhwc          p = {in, out}           i = {out_ld, out_dtype, B, C, H, W} */
+#define DSVC_SCAN_NHWC_TO_NCHW 11   /* u.call: dsvc_nhwc_to_nchw          p = {in, out}           i = {in_ld, in_dtype, B, C, H, W} */
+#define DSVC_SCAN_SE_GATE 12        /* u.call: dsvc_se_gate               p = {x, w1, w2, partial, gate}  i = {ld, dtype, B, H, W, C, hidden} */
+typedef struct dsvc_scan_call {     /* argument block of the pointwise / layout ops above */
+    const void* p[6];
+    int32_t i[10];
+    float f[2];
+} dsvc_scan_call;
 typedef struct dsvc_scan_op {
     int32_t kind;           /* DSVC_SCAN_* */
     int32_t reserved;
-    union { dsvc_conv_desc conv; dsvc_scan_gc gc; dsvc_scan_eb eb; dsvc_scan_ew ew; } u;
+    union { dsvc_conv_desc conv; dsvc_scan_gc gc; dsvc_scan_eb eb; dsvc_scan_ew ew; dsvc_scan_call call; } u;
 } dsvc_scan_op;
 int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int32_t n_ops);
+
+/* Frame level (SURVEY.md section 8b "frame level (later)": dsvc_pframe_compress / dsvc_pframe_decompress).
+ * The reference's unit of work is one call -- DeepSVC.compress (video_model.py:137-151) / DeepSVC.decompress (:153-167) -- behind
+ * which PyTorch issues ~400 kernels one by one.  Here a P-frame is a handful of host-synchronisation-free SEGMENTS (encoder:
+ * motion estimation + motion analysis + scan | synthesis + prediction + feature extraction + residual analysis + scan; decoder:
+ * motion synthesis + prediction | residual synthesis | reconstruction; the range coder runs on the host between them, by format),
+ * each recorded ONCE as an array of dsvc_scan_op over (a) the caller's frame tensors, (b) one workspace arena in which the
+ * segment's temporaries are packed by lifetime, (c) the model's packed weights; per frame the host layer patches the pointers of
+ * the frame tensors into the array and makes ONE call per segment.  The library issues the segment's launches back to back on
+ * `stream` (stream-ordered, no host synchronisation); results are those of the same ops issued one by one. */
+int dsvc_pframe_segment_run(void* stream, const dsvc_scan_op* ops, int32_t n_ops);
 
 /* ------------------------------------------------------------------------------------------
  * HOST: integer CDF construction and the range coder (compressai 1.2.1 _CXX / ans; Appendix A.4/A.5)

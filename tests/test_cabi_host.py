@@ -196,7 +196,7 @@ def test_scan_op_ctypes_mirrors_match_the_header(tmp_path):
     field offsets from gcc against the ctypes mirrors in deepsvc_amd/_native.py."""
     import ctypes
     import subprocess
-    structs = {"dsvc_scan_gc": N.ScanGc, "dsvc_scan_eb": N.ScanEb, "dsvc_scan_ew": N.ScanEw, "dsvc_scan_op": N.ScanOp}
+    structs = {"dsvc_scan_gc": N.ScanGc, "dsvc_scan_eb": N.ScanEb, "dsvc_scan_ew": N.ScanEw, "dsvc_scan_call": N.ScanCall, "dsvc_scan_op": N.ScanOp}
     lines = []
     for cname, cls in structs.items():
         for f, _ in cls._fields_:
@@ -212,5 +212,53 @@ def test_scan_op_ctypes_mirrors_match_the_header(tmp_path):
         for f, _ in cls._fields_:
             assert getattr(cls, f).offset == int(got[f"{cname}.{f}"]), f"{cname}.{f}: ctypes offset {getattr(cls, f).offset} != C {got[cname + '.' + f]}"
     # the union's members all start at the union's offset
-    assert N._ScanU.conv.offset == N._ScanU.gc.offset == N._ScanU.eb.offset == N._ScanU.ew.offset == 0
-    assert ctypes.sizeof(N._ScanU) == max(ctypes.sizeof(c) for c in (N.ConvDesc, N.ScanGc, N.ScanEb, N.ScanEw))
+    assert N._ScanU.conv.offset == N._ScanU.gc.offset == N._ScanU.eb.offset == N._ScanU.ew.offset == N._ScanU.call.offset == 0
+    assert ctypes.sizeof(N._ScanU) == max(ctypes.sizeof(c) for c in (N.ConvDesc, N.ScanGc, N.ScanEb, N.ScanEw, N.ScanCall))
+    # every op kind maps to a union member, and the pointer finder sees the pointers of each member
+    assert set(N.SCAN_UNION_MEMBER.values()) == {"conv", "gc", "eb", "ew", "call"}
+    assert len(N.pointer_offsets(N.ConvDesc)) == 11 and len(N.pointer_offsets(N.ScanCall)) == 6 and len(N.pointer_offsets(N.ScanEw)) == 6
+
+
+def test_frame_program_packs_temporaries_by_lifetime_and_relocates_pointers():
+    """ops.FrameProgram (host logic of dsvc_pframe_segment_run), on CPU tensors -- no launch: temporaries whose lifetimes (first ..
+    last op touching them) overlap get disjoint arena ranges, those that do not may share; pointers into externals are patched per
+    run, pointers into persistent tensors stay as recorded."""
+    import ctypes
+    import torch
+    from deepsvc_amd import ops
+
+    rec = ops.ScanRecorder()
+    mk = lambda n: torch.zeros(n, dtype=torch.uint8)
+    ext_in, persistent_w = mk(4096), mk(1024)
+    t = [mk(1000), mk(3000), mk(2000), mk(500)]          # lifetimes (ops): t0 [0,1], t1 [1,2], t2 [2,3], t3 [3,3]
+    out = ops.Act(torch.zeros((1, 2, 2, 8), dtype=torch.float32))
+    rec.temps += t + [out.buf]
+
+    def ew(a, b, o):                                       # an eltwise op: out = f(a, b)
+        w = N.ScanEw()
+        w.a.ptr, w.b.ptr, w.out = a, b, o
+        rec.add(N.SCAN_ELTWISE, "ew", w, [])
+    ew(ext_in.data_ptr() + 16, persistent_w.data_ptr(), t[0].data_ptr())
+    ew(t[0].data_ptr(), persistent_w.data_ptr() + 8, t[1].data_ptr() + 32)
+    ew(t[1].data_ptr(), None, t[2].data_ptr())
+    ew(t[2].data_ptr(), t[3].data_ptr(), out.ptr)
+    prog = ops.FrameProgram(rec, [ext_in], [out], [])
+    arr, base = prog.arr, prog.arena.data_ptr()
+    got = lambda i, f: getattr(arr[i].u.ew, f).ptr if f != "out" else arr[i].u.ew.out
+    off = {0: got(0, "out") - base, 1: got(1, "out") - 32 - base, 2: got(2, "out") - base, 3: got(3, "b") - base}
+    assert got(1, "a") - base == off[0] and got(2, "a") - base == off[1] and got(3, "a") - base == off[2]       # producer / consumer see one address
+    size = {0: 1000, 1: 3000, 2: 2000, 3: 500}
+    live = {0: (0, 1), 1: (1, 2), 2: (2, 3), 3: (3, 3)}
+    for i in range(4):
+        assert 0 <= off[i] and off[i] + size[i] <= prog.arena.numel() and off[i] % 512 == 0
+        for j in range(i + 1, 4):
+            if not (live[i][1] < live[j][0] or live[j][1] < live[i][0]):
+                assert off[i] + size[i] <= off[j] or off[j] + size[j] <= off[i], f"temporaries {i} and {j} are live together but overlap"
+    assert prog.arena_bytes < sum(-(-s // 512) * 512 for s in size.values()), "lifetime packing reused nothing"
+    assert got(0, "b") == persistent_w.data_ptr() and got(1, "b") == persistent_w.data_ptr() + 8                 # persistent: untouched
+    # externals: input slot 0 and the fresh output (slot 1) are patched by run(); emulate the patching without a launch
+    new_in, new_out = mk(4096), torch.zeros((1, 2, 2, 8), dtype=torch.float32)
+    bases = [new_in.data_ptr(), new_out.data_ptr()]
+    for cell, slot, delta in prog.ext_rel:
+        cell.value = bases[slot] + delta
+    assert got(0, "a") == new_in.data_ptr() + 16 and got(3, "out") == new_out.data_ptr()

@@ -448,3 +448,58 @@ def test_4k_gop12_with_intra_key_frame_f16():
         assert bool(torch.isfinite(t).all()) and float(bpp.min()) > 0.05 and float(t[1:, 4].min()) > 8.0
     finally:
         ops.set_precision("fp32")
+
+
+def test_frame_programs_equal_launch_by_launch_issue():
+    """DeepSVC.compress / decompress as recorded frame segments (five C calls per frame, include/dsvc.h: dsvc_pframe_segment_run)
+    against the same model issuing every launch from Python: identical strings, bit-identical decoded frames and features over
+    four chained P-frames (first + steady state; calls 2.. replay the recordings), in both precision modes; and an in-place weight
+    edit drops the recordings."""
+    from deepsvc_amd import ops, synth
+    size = 192
+    fr = [f.to(DEV) for f in synth.make_frames(size, size, 5)]
+    sms = [None] + [synth.make_sm_fea(size, size, t).to(DEV) for t in range(1, 5)]
+    for mode in ("fp32", "f16"):
+        ops.set_precision(mode)
+        try:
+            outs = {}
+            for name, flag in (("eager", False), ("programs", True)):
+                old = ops.FRAME_PROGRAMS[0]
+                ops.FRAME_PROGRAMS[0] = flag
+                try:
+                    m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+                    rows = []
+                    for rep in range(2):                     # the second pass over the GOP runs entirely on replayed programs
+                        ref, feat = fr[0], None
+                        for t in range(1, 5):
+                            mv, res = m.compress(ref, fr[t], sms[t], feat)
+                            mv, res = dict(mv.items()), dict(res.items())
+                            feat, ref, warped, predict = m.decompress(ref, mv, res, sms[t], feat)
+                            if rep == 1:
+                                rows.append((mv["strings"], res["strings"], feat.float().clone(), ref.clone(), warped.clone(), predict.clone()))
+                    if flag:
+                        progs = m.__dict__["_frame_programs"]
+                        kinds = sorted({k[0] for k, v in progs.items() if v})
+                        assert kinds == ["D1", "D2", "DR", "E1", "E2"], f"segments that did not become programs: {progs.keys()}"
+                        arena = sum(v.arena_bytes for v in progs.values() if v) / 2**20
+                        temps = sum(v.temp_bytes for v in progs.values() if v) / 2**20
+                        print(f"[frame programs] {mode}: {len(progs)} programs, {sum(v.n for v in progs.values() if v)} ops, arenas {arena:.1f} MiB for {temps:.1f} MiB of temporaries")
+                        assert arena < 0.7 * temps
+                    outs[name] = (rows, m)
+                finally:
+                    ops.FRAME_PROGRAMS[0] = old
+            for t, (a, b) in enumerate(zip(outs["eager"][0], outs["programs"][0]), 1):
+                assert a[0] == b[0] and a[1] == b[1], f"{mode} frame {t}: strings differ"
+                for x, y, what in zip(a[2:], b[2:], ("feature", "recon", "warped", "predict")):
+                    assert torch.equal(x, y), f"{mode} frame {t}: {what} differs between replayed segments and launch-by-launch issue"
+            # weight edit on the warmed program model: the next call must see it
+            m = outs["programs"][1]
+            mv, res = m.compress(fr[0], fr[1], sms[1], None)
+            mv, res = dict(mv.items()), dict(res.items())
+            before = m.decompress(fr[0], mv, res, sms[1], None)[1].clone()
+            with torch.no_grad():
+                m.enhance.recon_conv1.bias.add_(0.125)
+            after = m.decompress(fr[0], mv, res, sms[1], None)[1]
+            assert not torch.equal(before, after), "the replayed D2 segment ignored the weight edit"
+        finally:
+            ops.set_precision("fp32")

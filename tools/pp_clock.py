@@ -42,4 +42,5 @@ for name, kw in CASES:
     ghz = dt / max(dr, 1) * 0.1
     loop_us = dr / max(cnt, 1) / 100.0
     print(f"{name:28s} {us:7.1f} us per launch, tile loop {loop_us:6.1f} us, in-kernel clock {ghz:.3f} GHz "
-          f"-> {154.0e9 / us / 1e6:.3f} PFLOP/s = {154.0e9 / us / 1e6 / (2.5 * ghz / 2.4):.2f} of the MFMA rate available at that clock", flush=True)
+          f"-> {154.0e9 / us / 1e6:.1f} TFLOP/s = {154.0e9 / us / 1e6 / (2500.0 * ghz / 2.4):.2f} of the MFMA rate available at that clock "
+          f"({2500.0 * ghz / 2.4:.0f} TFLOP/s)", flush=True)
