@@ -19,6 +19,18 @@ from .modules import (ME_Spynet, RefineNet, Reconstruction, FeatureExtraction, I
 from .ops import Act, to_act
 
 F32 = torch.float32
+# The motion decode chain on its own stream (overlapping the encoder's tail when compress() / decompress() are called back to back):
+# +1-2 % with ONE GOP in flight, -7..9 % with four lanes (12 streams share the process's 4 hardware queues): opt-in.
+MV_STREAM = [__import__("os").environ.get("DSVC_MV_STREAM", "") != ""]
+HOST_TRACE = None          # tools/host_profile_1080p.py sets a list: (label, perf_counter) stamps of the host thread inside compress / decompress
+
+
+def _stamp(label):
+    if HOST_TRACE is not None:
+        import time
+        HOST_TRACE.append((label, time.perf_counter()))
+
+
 _DECODE_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="dsvc-resdec")   # one per concurrent GOP lane (bench.py --lanes)
 
 
@@ -169,6 +181,7 @@ class DeepSVC(nn.Module):
     @torch.no_grad()
     def compress(self, ref_frame, curr_frame, sm_fea, feature=None):
         """video_model.py:137-151 -> (mv_out_enc, res_out_enc), each {"strings": [[y],[z...]], "shape": (h,w)}."""
+        _stamp("compress")
         ref, cur = to_act(ref_frame), to_act(curr_frame)
         self._maybe_capture_graphs(ref)
         feat = self._feature_in(feature)
@@ -182,9 +195,11 @@ class DeepSVC(nn.Module):
             self.mv_codec.enc_gpu([cur, mv_est, ref], ws_mv)
             return [], []
 
-        def e2(ref, cur, sm, *f):
+        def e2a():
             # (the reference entropy-decodes its own mv stream here, video_model.py:141: y_hat is already on the device)
-            mv_coarse = self.mv_codec._g_s(ws_mv.y_hat, None, F32)
+            return [], [self.mv_codec._g_s(ws_mv.y_hat, None, F32)]
+
+        def e2(ref, cur, sm, mv_coarse, *f):
             _, _, predict = self._predict(ref, mv_coarse, sm, f[0] if f else None)
             predict_fea = self.FeatureExtractor.run(predict)
             cur_fea = self.FeatureExtractor.run(cur)
@@ -195,7 +210,12 @@ class DeepSVC(nn.Module):
         ops.run_segment(cache, ("E1", key), [ref, cur], e1)
         # the mv streams are range-coded on a worker thread while the GPU runs prediction + the residual analysis
         mv_pending = self.mv_codec.enc_finish(ws_mv, defer=True)
-        ops.run_segment(cache, ("E2", key), [ref, cur, sm_fea] + opt, e2)
+        _, (mv_coarse,) = ops.run_segment(cache, ("E2a", key), [], e2a)
+        # from here on nothing of the encoder touches the motion codec's scan workspace: the decoder's motion chain of this frame may
+        # start on its own stream while the rest of the encoder still runs (decompress())
+        done = self.__dict__["_mv_ws_free"] = torch.cuda.Event()
+        done.record()
+        ops.run_segment(cache, ("E2", key), [ref, cur, sm_fea, mv_coarse] + opt, e2)
         res_pending = self.res_codec.enc_finish(ws_res, defer=True)
         # both are dicts that join their coder thread on first access: a caller that forwards them to decompress()
         # without looking inside overlaps the residual range coding with the decoder's motion path
@@ -204,6 +224,7 @@ class DeepSVC(nn.Module):
     @torch.no_grad()
     def decompress(self, ref_frame, mv_out_enc, res_out_enc, sm_fea, feature):
         """video_model.py:153-167 -> (feature, recon, warped, predict), the three frames clamped to [0,1]."""
+        _stamp("decompress")
         ref = to_act(ref_frame)
         dev = ref.device
         self._maybe_capture_graphs(ref)
@@ -228,7 +249,26 @@ class DeepSVC(nn.Module):
             return out
 
         res_future = _DECODE_POOL.submit(decode_residual)
-        ws_mv = self.mv_codec.dec_chain(mv_out_enc["strings"], mv_out_enc["shape"], dev)
+        # The motion decode chain (host range decoder <-> tiny scan kernels, one sync per level) depends on the mv STRINGS only, not on
+        # anything the GPU is still doing for the encoder: with MV_STREAM it runs on its own high-priority stream, so when compress() of
+        # this frame has just been queued (test_video.py:342,349 calls them back to back) part of its latency hides under the encoder's
+        # remaining kernels (tiny kernels only get CU slots at the boundaries of the large ones, so the chain advances one launch per
+        # large kernel: measured 7.9 ms for the chain beside E2 against ~4.5 ms alone).
+        import os
+        mvs = main if not MV_STREAM[0] else self.__dict__.setdefault("_mv_streams", {}).get(str(dev))
+        if mvs is None:
+            mvs = self.__dict__["_mv_streams"][str(dev)] = torch.cuda.Stream(dev, priority=int(os.environ.get("DSVC_MV_STREAM_PRIO", "-1")))
+        free = self.__dict__.get("_mv_ws_free")
+        with torch.cuda.stream(mvs):
+            if free is not None:
+                mvs.wait_event(free)                # the encoder has finished reading the shared scan workspace (y_hat)
+            else:
+                mvs.wait_stream(main)
+            mv_strings = mv_out_enc["strings"]
+            _stamp("mv strings joined")
+            ws_mv = self.mv_codec.dec_chain(mv_strings, mv_out_enc["shape"], dev)
+            _stamp("mv chain done")
+        main.wait_stream(mvs)
 
         def d1(ref, sm, *f):
             mv_coarse = self.mv_codec._g_s(ws_mv.y_hat, None, F32)
@@ -248,7 +288,9 @@ class DeepSVC(nn.Module):
             return [fea, clamp(recon), clamp(warped), clamp(predict)], []
 
         _, (warped, warp_fea, predict, predict_fea) = ops.run_segment(cache, ("D1", key), [ref, sm_fea] + opt, d1)
+        _stamp("D1 queued")
         res_coarse = res_future.result()
+        _stamp("res chain done")
         main.wait_event(res_done)
         res_coarse.buf.record_stream(main)
         (fea, recon_c, warped_c, predict_c), _ = ops.run_segment(cache, ("D2", key), [ref, warped, warp_fea, predict, predict_fea, res_coarse], d2)

@@ -480,7 +480,7 @@ def test_frame_programs_equal_launch_by_launch_issue():
                     if flag:
                         progs = m.__dict__["_frame_programs"]
                         kinds = sorted({k[0] for k, v in progs.items() if v})
-                        assert kinds == ["D1", "D2", "DR", "E1", "E2"], f"segments that did not become programs: {progs.keys()}"
+                        assert kinds == ["D1", "D2", "DR", "E1", "E2", "E2a"], f"segments that did not become programs: {progs.keys()}"
                         arena = sum(v.arena_bytes for v in progs.values() if v) / 2**20
                         temps = sum(v.temp_bytes for v in progs.values() if v) / 2**20
                         print(f"[frame programs] {mode}: {len(progs)} programs, {sum(v.n for v in progs.values() if v)} ops, arenas {arena:.1f} MiB for {temps:.1f} MiB of temporaries")
