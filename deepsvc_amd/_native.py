@@ -37,6 +37,7 @@ class ConvDesc(Structure):
         ("s2d", c_int32),
         ("post_weight", c_void_p), ("post_bias", c_void_p),
         ("batch_inner", c_int32), ("weight_bstride", c_int64), ("bias_bstride", c_int64), ("in_bstride", (c_int64 * 2) * 3),
+        ("out_bstride", c_int64), ("res1_bstride", c_int64),
     ]
 
 

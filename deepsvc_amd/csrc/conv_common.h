@@ -37,6 +37,7 @@ struct ConvParams {
     int regepi;                                    // 1: conv_mfma_kernel's register epilogue variant
     unsigned w_bytes;                              // extent of one item's packed weights (buffer-resource bound)
     long long w_bs; int bias_bs;                   // per-batch-item weights (dsvc.h: weight_bstride): bytes / floats per item, 0 = shared
+    long long out_bs, res1_bs;                     // per-item output / residual placement (dsvc.h: out_bstride), 0 = dense batch
 };
 
 // ---- raw buffer resources: hardware bounds checking instead of branches ------------------------------------------

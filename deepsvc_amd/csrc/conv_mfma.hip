@@ -530,7 +530,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     constexpr int EPM = MT >= 2 ? 2 : 1;            // output rows per pass (the slab of a 16-row tile would not leave room for a second workgroup)
     constexpr int EPC = EPN * 32, EPLD = EPC + 4, GPP = EPC / 4;
     float* slab = (float*)smem + (size_t)wave * (EPM * 32 * EPLD);
-    const EpiRsrc R = make_epi_rsrc(p);
+    // per-item output placement (dsvc.h: out_bstride): this item's output / residual / bias become image 0 of the epilogue's view
+    ConvParams pe = p;
+    int be = b;
+    if (p.out_bs) {
+        pe.out = (char*)p.out + (size_t)b * p.out_bs;
+        if (p.res1) pe.res1 = (const char*)p.res1 + (size_t)b * p.res1_bs;
+        if (p.bias) pe.bias = p.bias + (size_t)b * p.bias_bs;
+        pe.bias_bs = 0;
+        be = 0;
+    }
+    const EpiRsrc R = make_epi_rsrc(pe);
 #pragma unroll
     for (int n0 = 0; n0 < NT; n0 += EPN) {
 #pragma unroll
@@ -550,8 +560,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             }
             lds_barrier();
             const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
-            if (m0 + EPM <= MT) run_epilogue<GPP, EPLD, EPM * 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);
-            else run_epilogue<GPP, EPLD, 32>(p, R, slab, lane, b, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);     // odd last row
+            if (m0 + EPM <= MT) run_epilogue<GPP, EPLD, EPM * 32>(pe, R, slab, lane, be, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);
+            else run_epilogue<GPP, EPLD, 32>(pe, R, slab, lane, be, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);     // odd last row
         }
     }
     PROBE_FINISH
@@ -711,6 +721,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     }
     p.b_inner = per_item ? d->batch_inner : 0x7FFFFFFF;
     p.w_bs = per_item ? d->weight_bstride : 0; p.bias_bs = per_item ? (int)d->bias_bstride : 0;
+    const bool item_out = per_item && d->out_bstride > 0;
+    DSVC_REQUIRE(per_item || (d->out_bstride == 0 && d->res1_bstride == 0), "conv2d: out_bstride / res1_bstride need batch_inner > 0");
+    DSVC_REQUIRE(!item_out || (d->shuffle == 1 && !d->res2 && d->res1_bstride >= 0 && (d->res1 == nullptr || d->res1_bstride > 0)),
+                 "conv2d: out_bstride excludes shuffle / res2 and needs res1_bstride with res1");
+    p.out_bs = item_out ? d->out_bstride : 0; p.res1_bs = item_out ? d->res1_bstride : 0;
     p.nseg = d->nseg; p.nchunks = chunk0;
     p.B = d->B; p.H = d->H; p.W = d->W;
     p.s2d = d->s2d ? 1 : 0;
@@ -736,12 +751,12 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         const int bytes = 4 * dsvc_esize(dtype);
         return ptr != nullptr && ((uintptr_t)ptr % bytes) == 0 && (ld % 4) == 0;
     };
-    p.res1_vec = vec4_ok(d->res1, d->res1_ld, d->res1_dtype);
+    p.res1_vec = vec4_ok(d->res1, d->res1_ld, d->res1_dtype) && (!item_out || d->res1_bstride % (4 * dsvc_esize(d->res1_dtype)) == 0);
     p.res2_vec = vec4_ok(d->res2, d->res2_ld, d->res2_dtype);
-    p.out_vec = vec4_ok(d->out, d->out_ld, d->out_dtype);
+    p.out_vec = vec4_ok(d->out, d->out_ld, d->out_dtype) && (!item_out || d->out_bstride % (4 * dsvc_esize(d->out_dtype)) == 0);
     {
         const int sh = d->shuffle;
-        const int64_t opix = (int64_t)d->B * p.Ho * sh * p.Wo * sh, oc = d->Cout / (sh * sh);
+        const int64_t opix = (int64_t)(item_out ? 1 : d->B) * p.Ho * sh * p.Wo * sh, oc = d->Cout / (sh * sh);      // per-item placement: one image per item
         const int64_t oe = ((opix - 1) * d->out_ld + oc) * dsvc_esize(d->out_dtype);
         const int64_t r1e = d->res1 ? ((opix - 1) * d->res1_ld + oc) * dsvc_esize(d->res1_dtype) : 0;
         const int64_t r2e = d->res2 ? ((opix - 1) * d->res2_ld + oc) * dsvc_esize(d->res2_dtype) : 0;
@@ -828,7 +843,7 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
 
     {
         auto al16 = [](const void* q, int ld) { return ((uintptr_t)q & 15) == 0 && (ld % 8) == 0; };
-        p.regepi = opt.reg_epilogue && fast && d->compute == DSVC_F16 && (MT == 4 || (MT == 2 && NT >= 2)) && d->out_dtype == DSVC_F16 &&
+        p.regepi = opt.reg_epilogue && !item_out && fast && d->compute == DSVC_F16 && (MT == 4 || (MT == 2 && NT >= 2)) && d->out_dtype == DSVC_F16 &&
                    d->shuffle == 1 && (d->Cout % 32) == 0 && al16(d->out, d->out_ld) && !d->res2 && !d->res1_scale &&
                    (!d->res1 || (d->res1_dtype == DSVC_F16 && al16(d->res1, d->res1_ld))) &&
                    (d->act == DSVC_ACT_NONE || d->act == DSVC_ACT_RELU || (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f));

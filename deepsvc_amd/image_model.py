@@ -25,6 +25,7 @@ from .modules import Conv2d, Deconv5x5s2, ResBottleneckBlock, conv, get_scale_ta
 from .ops import Act, to_act
 
 F32 = torch.float32
+ITEM_LRP = __import__("os").environ.get("DSVC_NO_ITEM_LRP", "") == ""     # A/B switch: LRP stacks of the last level + the hyper-synthesis pair as batch items
 _CODER_POOL = ThreadPoolExecutor(max_workers=12, thread_name_prefix="dsvc-rans")   # ctypes calls release the GIL; 2 per GOP lane, up to 6 lanes
 
 
@@ -318,6 +319,64 @@ class ChannelSplitICIP2020ResB(nn.Module):
             fns.append(lambda i=i: self._stack(self.cc_scale_transforms[i], self._support(ws.scales, ws.y_hat, i), out=ws.scs[i]))
         ops.run_parallel(fns)
 
+    def _packed_items(self, tag, stacks, segC, device):
+        """Per layer, the ItemPackedConv of several shape-identical conv stacks (`stacks`: lists of Conv2d / Sequential(Conv2d, PixelShuffle)
+        wrappers are unwrapped by the caller).  Cached; rebuilt (and this codec's graphs invalidated) when a layer has been repacked."""
+        cache = self.__dict__.setdefault("_item_cache", {})
+        key = (tag, tuple(segC), ops.RT.compute, str(device))
+        out = []
+        for l in range(len(stacks[0])):
+            packs = [st[l]._packed(list(segC) if l == 0 else [st[l].in_channels], device) for st in stacks]
+            ipc = cache.get(key + (l,))
+            if ipc is None or any(a is not b for a, b in zip(ipc.sources, packs)):
+                ipc = cache[key + (l,)] = ops.ItemPackedConv(packs)
+                self._epoch_ref()[0] += 1
+            out.append(ipc)
+        return out
+
+    def _lrp_group(self, ws, group):
+        """The latent-residual-prediction stacks of one dependency level.  The slices of the LAST level (4 of the 8, 5 of the I-frame
+        codec's 10) share their support and differ only in their own y_hat slice, which is also where each writes: they run as the
+        batch items of one launch per layer (include/dsvc.h: batch_inner with out_bstride) -- 3 launches instead of 12 / 15."""
+        d, k = self.slice_depth, self.max_support_slices
+        y_hat, means = ws.y_hat, self._latent_seg(ws.means)
+        esz = y_hat.buf.element_size()
+        cur0 = y_hat.ch(group[0] * d, d)
+        segs = [means, y_hat.ch(0, k * d), cur0]
+        ok = (ops.ITEM_SCAN[0] and ITEM_LRP and ws.B == 1 and len(group) > 1 and group[0] >= k and group == list(range(group[0], group[0] + len(group)))
+              and ops.items_ok(segs) and (d * esz) % 16 == 0)
+        if not ok:
+            ops.run_parallel([(lambda i=i: self._lrp(i, ws.means, y_hat)) for i in group])
+            return
+        G = len(group)
+        stacks = [[m for m in self.lrp_transforms[i] if isinstance(m, Conv2d)] for i in group]
+        ipcs = self._packed_items(("lrp", tuple(group)), stacks, [a.C for a in segs], ws.device)
+        hidden, slope = self._stack_act
+        x = ops.conv2d(ipcs[0], segs, act=hidden, slope=slope, out_dtype=ops.RT.storage, items=(G, [(0, 0), (0, 0), (d * esz, 0)]))
+        for ipc in ipcs[1:-1]:
+            x = ops.conv2d(ipc, [x], act=hidden, slope=slope, out_dtype=ops.RT.storage, items=(G, [(x.H * x.W * x.ld * x.buf.element_size(), 0)]))
+        ops.conv2d(ipcs[-1], [x], cur0, act=N.ACT_HALF_TANH, res1=cur0, out_dtype=F32,
+                   items=(G, [(x.H * x.W * x.ld * x.buf.element_size(), 0)]), item_out=(d * esz, d * esz))
+
+    def _hyper_into(self, ws):
+        """h_scale_s(z_hat) -> ws.scales and h_mean_s(z_hat) -> ws.means.  The two nets have identical shapes and the two outputs are
+        neighbours in one buffer (`ws.pair`): with one image in flight they run as two batch items of one launch per layer."""
+        nets = [self.h_mean_s, self.h_scale_s]                        # item order = ws.pair's: means | scales
+        convs = [[m[0] if isinstance(m, nn.Sequential) else m for m in net if isinstance(m, (Conv2d, nn.Sequential))] for net in nets]
+        plain = type(self)._h_s is ChannelSplitICIP2020ResB._h_s and all(isinstance(c, Conv2d) for st in convs for c in st) and len(convs[0]) == 4
+        if not (plain and ops.ITEM_SCAN[0] and ITEM_LRP and ws.B == 1 and ops.items_ok([ws.z_hat])):
+            ops.run_parallel([lambda: self._h_s(self.h_scale_s, ws.z_hat, ws.scales), lambda: self._h_s(self.h_mean_s, ws.z_hat, ws.means)])
+            return
+        ipcs = self._packed_items(("h_s",), convs, [ws.z_hat.C], ws.device)
+        shuf = [2 if isinstance(m, nn.Sequential) else 1 for m in self.h_mean_s if isinstance(m, (Conv2d, nn.Sequential))]
+        x, first = ws.z_hat, True
+        for l, ipc in enumerate(ipcs):
+            last = l == len(ipcs) - 1
+            stride = 0 if first else x.H * x.W * x.ld * x.buf.element_size()
+            x = ops.conv2d(ipc, [x], ops.Act(ws.pair.buf, 0, ws.means.C) if last else None, act=N.ACT_NONE if last else N.ACT_GELU, shuffle=shuf[l],
+                           out_dtype=F32, items=(2, [(stride, 0)]))
+            first = False
+
     def _lrp(self, i, means, y_hat):
         """y_hat_i += 0.5*tanh(lrp_i(cat[mean_support, y_hat_i])) in place (image_model.py:185-188,244-247,292-295)."""
         d = self.slice_depth
@@ -477,8 +536,7 @@ class ChannelSplitICIP2020ResB(nn.Module):
 
         def dec_first():
             ops.eb_dequantize(ws.z_sym, eb.device_params(device), ws.z_hat)
-            ops.run_parallel([lambda: self._h_s(self.h_scale_s, ws.z_hat, ws.scales),
-                              lambda: self._h_s(self.h_mean_s, ws.z_hat, ws.means)])
+            self._hyper_into(ws)
             self._dec_nets(ws, groups[0])
 
         def dec_level(group, nxt):
@@ -498,19 +556,16 @@ class ChannelSplitICIP2020ResB(nn.Module):
         d, nz, ny, ns = self.slice_depth, ws.nz, ws.ny, ws.ns
         z = self._h_a(ws.y)
         eb.quantize(z, True, ws.z_hat, sym_out=ws.staging[:nz])
-        ops.run_parallel([lambda: self._h_s(self.h_scale_s, ws.z_hat, ws.scales),
-                          lambda: self._h_s(self.h_mean_s, ws.z_hat, ws.means)])
+        self._hyper_into(ws)
         table = gc.device_table(ws.device)
 
-        def code_slice(i):
-            ops.gc_quantize(ws.y.ch(i * d, d), ws.mus[i], ws.scs[i], table, True, True, ws.y_hat.ch(i * d, d),
-                            sym_out=ws.staging[nz + i * ns: nz + (i + 1) * ns],
-                            idx_out=ws.staging[nz + ny + i * ns: nz + ny + (i + 1) * ns])
-            self._lrp(i, ws.means, ws.y_hat)
-
-        for group in ws.groups:       # slices of one dependency level are independent: forked onto parallel streams
+        for group in ws.groups:       # slices of one dependency level are independent: their stacks run as batch items
             self._group_params(ws, group)
-            ops.run_parallel([(lambda i=i: code_slice(i)) for i in group])
+            for i in group:
+                ops.gc_quantize(ws.y.ch(i * d, d), ws.mus[i], ws.scs[i], table, True, True, ws.y_hat.ch(i * d, d),
+                                sym_out=ws.staging[nz + i * ns: nz + (i + 1) * ns],
+                                idx_out=ws.staging[nz + ny + i * ns: nz + ny + (i + 1) * ns])
+            self._lrp_group(ws, group)
 
     def enc_gpu(self, segments, ws=None):
         """GPU half of compress(): analysis transform into the scan workspace + the whole encoder scan (no host interaction)."""
@@ -565,11 +620,9 @@ class ChannelSplitICIP2020ResB(nn.Module):
         """symbols of one level -> y_hat slices (+ latent residual prediction)."""
         d, n = self.slice_depth, ws.ns
 
-        def one(j, i):
+        for j, i in enumerate(group):
             ops.gc_dequantize(ws.sym_dev[j * n:(j + 1) * n], ws.mus[i], ws.y_hat.ch(i * d, d))
-            self._lrp(i, ws.means, ws.y_hat)
-
-        ops.run_parallel([(lambda j=j, i=i: one(j, i)) for j, i in enumerate(group)])
+        self._lrp_group(ws, group)
 
     def run_decompress(self, strings, shape, device, x_hat_out=None, x_hat_dtype=None):
         ws = self.dec_chain(strings, shape, device)

@@ -509,13 +509,14 @@ def profile_end():
 
 
 def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.01, res1=None, gate=None, res2=None,
-           shuffle=1, out_dtype=None, post=None, items=None):
+           shuffle=1, out_dtype=None, post=None, items=None, item_out=None):
     """Run one fused conv.  inputs: list of Act (virtual torch.cat along channels).
     items=(inner, [(stride_lo, stride_hi) per input, bytes]) with an ItemPackedConv `pc`: pc.items independent convs in one
     launch (include/dsvc.h: batch_inner); every input Act is item 0's image, the output is a dense [items, H, W, C] Act."""
     x0 = inputs[0]
     if items is not None:
-        return _conv2d_items(pc, inputs, out, items, act=act, pre_act=pre_act, slope=slope, res1=res1, shuffle=shuffle, out_dtype=out_dtype)
+        return _conv2d_items(pc, inputs, out, items, act=act, pre_act=pre_act, slope=slope, res1=res1, shuffle=shuffle, out_dtype=out_dtype,
+                             item_out=item_out)
     _require_gpu(x0.buf)
     s2d = getattr(pc, "s2d", False)
     mult = 4 if s2d else 1
@@ -571,7 +572,9 @@ def conv2d(pc, inputs, out=None, *, act=N.ACT_NONE, pre_act=N.ACT_NONE, slope=0.
     return out
 
 
-def _conv2d_items(pc, inputs, out, items, *, act, pre_act, slope, res1, shuffle, out_dtype):
+def _conv2d_items(pc, inputs, out, items, *, act, pre_act, slope, res1, shuffle, out_dtype, item_out=None):
+    """item_out = (out_bstride, res1_bstride) in bytes: `out` (and `res1`) are item 0's single-image Acts and item b's sit b strides further
+    (include/dsvc.h: out_bstride) -- e.g. consecutive channel slices of one buffer."""
     inner, strides = items
     x0 = inputs[0]
     _require_gpu(x0.buf)
@@ -580,6 +583,9 @@ def _conv2d_items(pc, inputs, out, items, *, act, pre_act, slope, res1, shuffle,
     Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
     Wo = (W + 2 * pc.pad - pc.kw) // pc.stride + 1
     oshape = (G, Ho * shuffle, Wo * shuffle, pc.Cout // (shuffle * shuffle))
+    if item_out is not None:
+        oshape = (1,) + oshape[1:]
+        assert out is not None
     if out is None:
         out = new_act(*oshape, out_dtype, x0.device)
     assert (out.B, out.H, out.W, out.C) == oshape, f"out shape {(out.B, out.H, out.W, out.C)} != {oshape}"
@@ -600,6 +606,8 @@ def _conv2d_items(pc, inputs, out, items, *, act, pre_act, slope, res1, shuffle,
         d.res1, d.res1_ld, d.res1_dtype = res1.ptr, res1.ld, res1.code
     d.shuffle = shuffle
     d.out, d.out_ld, d.out_dtype = out.ptr, out.ld, out.code
+    if item_out is not None:
+        d.out_bstride, d.res1_bstride = item_out
     r = _rec()
     if r is not None:
         r.add(N.SCAN_CONV, "conv", d, [pc, out.buf] + [a.buf for a in inputs] + ([res1.buf] if res1 is not None else []))

@@ -128,6 +128,10 @@ typedef struct dsvc_conv_desc {
     int32_t batch_inner;
     int64_t weight_bstride, bias_bstride;
     int64_t in_bstride[3][2];
+    /* batch_inner > 0 only: out_bstride > 0 places item b's output (and residual res1, with res1_bstride) at out + b * out_bstride
+     * bytes as ONE image [H, W, ld] -- e.g. consecutive channel slices of one buffer: the latent-residual-prediction stacks of a scan
+     * level write y_hat slice after slice in place (image_model.py:185-188,244-247).  0 = the dense [B, H, W, ld] layout. */
+    int64_t out_bstride, res1_bstride;
 } dsvc_conv_desc;
 
 /* bytes of the packed weight buffer for a conv with these input segments */
