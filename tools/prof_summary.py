@@ -1,11 +1,11 @@
 """Turn the rocprofv3 CSVs that tools/collect_profiles.sh leaves under gpurun_out/<tag>/ into the summaries committed under
-profiles/ (round prefix r02):
+profiles/ (round prefix r03):
 
-  r02_bench_<run>_kernel_stats.csv          rocprofv3 --stats table of the run, verbatim
-  r02_bench_<run>_by_kernel_and_grid.csv    the same trace grouped by (kernel name, grid, workgroup): one row per launch SHAPE,
+  r03_bench_<run>_kernel_stats.csv          rocprofv3 --stats table of the run, verbatim
+  r03_bench_<run>_by_kernel_and_grid.csv    the same trace grouped by (kernel name, grid, workgroup): one row per launch SHAPE,
                                             so that a per-shape duration (hence a roofline fraction) can be re-derived
-  r02_bench_<run>_line.json                 the JSON line bench.py printed under the profiler
-  r02_dominant_kernel_pmc.json              HBM traffic per launch of the dominant conv (FETCH_SIZE / WRITE_SIZE from separate
+  r03_bench_<run>_line.json                 the JSON line bench.py printed under the profiler
+  r03_dominant_kernel_pmc.json              HBM traffic per launch of the dominant conv (FETCH_SIZE / WRITE_SIZE from separate
                                             --pmc passes, corrected as MI355X_MICROARCH.md prescribes) + MFMA-utilisation counters
 
     python tools/prof_summary.py gpurun_out/r2p
@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
-PRE = "r02"
+PRE = "r03"
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -118,7 +118,7 @@ if all(os.path.exists(p) for p in (pf, pw, ps)):
                 del S[key]
         n = len(fv)
         fkb, wkb = sum(fv) / n, sum(wv) / len(wv)
-        flags = [x.strip() == "true" for x in name[name.index("<") + 1:name.index(">")].split(",")[2:]]   # HEAD, PRE, ACT, R1, R2, POST
+        flags = [x.strip() == "true" for x in name[name.index("<") + 1:name.index(">")].split(",")[2:]]   # HEAD, PRE, ACT, R1, R2, POST, M16
         nres = int(flags[3]) + int(flags[4])
         alg = (2 + nres) * H * Wd * 64 * esz
         ent = {"launches": n, "FETCH_SIZE_KB_avg": fkb, "WRITE_SIZE_KB_avg": wkb,
@@ -141,8 +141,59 @@ if all(os.path.exists(p) for p in (pf, pw, ps)):
            "selection": "full-resolution launches only (WRITE_SIZE within 3 % of 1088*1920*64*2 B): the persistent kernel's name and grid are the same at 1/2 resolution",
            "note": "launch-weighted mean over the epilogue variants below (the `roofline` of the bench line averages the same launches); algorithmic = input + output (+ one tensor per residual operand), 2 bytes per element",
            "variants": variants}
+    def by_nres(entries):
+        """{residual operands: launch-weighted bytes per launch} -- what bench.py weights with its own launch mix"""
+        out = {}
+        for k in (0, 1, 2):
+            es = [e for e in entries if e["nres"] == k]
+            if es:
+                n = sum(e["launches"] for e in es)
+                out[str(k)] = {"launches": n,
+                               "hbm_bytes_per_launch_corrected": sum(e["hbm_bytes_per_launch_corrected"] * e["launches"] for e in es) / n,
+                               "algorithmic_bytes_per_launch": sum(e["algorithmic_bytes_per_launch"] * e["launches"] for e in es) / n}
+        return out
+
+    for name, v in variants.items():
+        fl = [x.strip() == "true" for x in name[name.index("<") + 1:name.index(">")].split(",")[2:]]
+        v["nres"] = int(fl[3]) + int(fl[4])
+    rec["by_residual_operands"] = by_nres(list(variants.values()))
+    full = {"f16": rec}
+    # ---- fp32 mode: the same conv shape on the generic kernel (conv_mfma_kernel<f32, MT=2, NT=2>, 8160 workgroups); the epilogue variant is a
+    # run-time parameter there, so launches are classed by how many 64-channel fp32 tensors they READ (1 + residual operands)
+    pf32, pw32 = (os.path.join(src, d, "p_counter_collection.csv") for d in ("pmc_fetch_f32", "pmc_write_f32"))
+    if os.path.exists(pf32) and os.path.exists(pw32):
+        F32c, W32c = counters(pf32), counters(pw32)
+        tensor = H * Wd * 64 * 4
+        entries = []
+        for key in F32c:
+            name, wgs = key
+            if not (name.startswith("conv_mfma_kernel<f32, MT=2, NT=2") or name.startswith("conv_mfma_kernel<float, 2, 2,")) or wgs != 8160 or key not in W32c:
+                continue
+            fv, wv = F32c[key]["FETCH_SIZE"], W32c[key]["WRITE_SIZE"]
+            if len(fv) != len(wv):
+                continue
+            groups = collections.defaultdict(list)
+            for f_kb, w_kb in zip(fv, wv):
+                if abs(w_kb * 1024 - tensor) > 0.03 * tensor:
+                    continue                               # another output width
+                reads = 2 * f_kb * 1024 / tensor
+                k = int(round(reads)) - 1
+                if k in (0, 1, 2) and abs(reads - (k + 1)) < 0.35:
+                    groups[k].append((2 * f_kb * 1024 + w_kb * 1024))
+            for k, vals in groups.items():
+                entries.append({"nres": k, "launches": len(vals), "hbm_bytes_per_launch_corrected": sum(vals) / len(vals),
+                                "algorithmic_bytes_per_launch": (2 + k) * tensor})
+        if entries:
+            n = sum(e["launches"] for e in entries)
+            full["fp32"] = {"kernel": "conv_mfma_kernel<f32, MT=2, NT=2, FAST=1>: 3x3 s1 64->64 launches @1088x1920 of one P-frame, fp32 storage "
+                                      "(launches reading 2 tensors include the few two-segment 64+64->64 convs of the same grid)",
+                            "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (one pass each) -- python3 bench.py --precision fp32 --lanes 1 --steps 2 --warmup 2 --no-side-legs --no-cpu-baseline",
+                            "launches": n,
+                            "hbm_bytes_per_launch_corrected": sum(e["hbm_bytes_per_launch_corrected"] * e["launches"] for e in entries) / n,
+                            "algorithmic_bytes_per_launch": sum(e["algorithmic_bytes_per_launch"] * e["launches"] for e in entries) / n,
+                            "by_residual_operands": by_nres(entries)}
     with open(os.path.join(OUT, f"{PRE}_dominant_kernel_pmc.json"), "w") as f:
-        json.dump(rec, f, indent=1)
+        json.dump(full, f, indent=1)
     # traffic of every kernel, for the pass-count table of DESIGN.md
     with open(os.path.join(OUT, f"{PRE}_bench_f16_pmc_traffic_by_kernel.csv"), "w", newline="") as f:
         w = csv.writer(f)
