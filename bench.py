@@ -328,7 +328,8 @@ def main():
     warm(lanes, args.warmup)
     t_max, durs_shared, hist_shared = timed(lanes, args.steps)
     rows = [r for L in lanes for r in L["rows"]]
-    hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30
+    hbm_peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30       # incl. the one-off recording pass of the frame segments (all temporaries alive at once)
+    hbm_steady_gb = torch.cuda.memory_allocated(dev) / 2**30       # what the lanes hold between frames: weights, workspaces, arenas, frames
 
     side = not args.no_side_legs
     lanes1 = parity = deltas = None
@@ -444,14 +445,14 @@ def main():
                                    + f"W0 synthetic PSNR weight set, compress+decompress per frame, GOPs sharded across ranks, {args.lanes} independent "
                                      f"GOP lane(s) in flight per GPU (one step = one frame on every lane)",
                        "precision": args.precision, "gop_lanes": args.lanes, "frames_per_step": args.lanes * world,
-                       "hbm_peak_gb": hbm_peak_gb, "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
+                       "hbm_peak_gb": hbm_peak_gb, "hbm_steady_gb": hbm_steady_gb, "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
                        "whole_frame_tflops": fps * FLOP_PER_PX[args.config] * H_pad * W_pad / 1e12 / world,
                        # the other legs of this run as scalars (details in the objects of the same names below)
                        "lanes1_fps": None if lanes1 is None else lanes1["value"],
                        "lanes1_ms_per_frame": None if lanes1 is None else lanes1["ms_per_step"],
                        "parity_mode_fp32_fps": None if parity is None else parity["value"],
                        "parity_mode_fp32_roofline_frac": None if parity is None or parity["roofline"] is None else parity["roofline"]["frac"],
-                       "f16_roofline_frac": None if roof is None else roof["frac"]},
+                       "roofline_frac": None if roof is None else roof["frac"]},
             "roofline": roof,
         }
         if lanes1 is not None:

@@ -129,6 +129,23 @@ class ScanProgram:
         N.check(N.lib().dsvc_entropy_scan_step(_stream(), ctypes.addressof(self.arr), self.n), "entropy_scan_step")
 
 
+class Arena:
+    """One workspace shared by the frame segments that run one after the other on the same stream: its size is the LARGEST of their
+    needs, not the sum.  Growing it re-patches the temporaries' pointers of every program registered with it."""
+
+    def __init__(self):
+        self.buf, self.programs = None, []
+
+    def attach(self, prog, nbytes, device):
+        self.programs.append(prog)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, FrameProgram.ALIGN), dtype=torch.uint8, device=device)
+            for p in self.programs:
+                p._patch_arena(self.buf.data_ptr())
+        else:
+            prog._patch_arena(self.buf.data_ptr())
+
+
 class FrameProgram:
     """A frozen recording of one host-synchronisation-free SEGMENT of a P-frame (include/dsvc.h: dsvc_pframe_segment_run).
 
@@ -143,8 +160,9 @@ class FrameProgram:
 
     ALIGN = 512
 
-    def __init__(self, rec, externals, fresh, persistent):
-        """externals: [Act | tensor] inputs in binding order; fresh: [Act] outputs reallocated per run; persistent: [Act] outputs kept."""
+    def __init__(self, rec, externals, fresh, persistent, arena=None):
+        """externals: [Act | tensor] inputs in binding order; fresh: [Act] outputs reallocated per run; persistent: [Act] outputs kept;
+        arena: an `Arena` shared with the other segments of the same stream (None: a private one)."""
         assert rec.poisoned is None
         self.n = len(rec.ops)
         self.arr = (N.ScanOp * max(self.n, 1))(*rec.ops)
@@ -218,15 +236,21 @@ class FrameProgram:
                     offset[k], top = top, top + need
             live.append((last[k], offset[k], need))
         dev = temps[0].device if temps else (ext[0].device if ext else None)
-        self.arena = torch.empty(max(top, self.ALIGN), dtype=torch.uint8, device=dev) if dev is not None else None
         self.arena_bytes, self.temp_bytes = top, sum(size(k) for k in order)
-        abase = self.arena.data_ptr() if self.arena is not None else 0
-        for addr, slot, delta in tmp_rel:
-            ctypes.c_uint64.from_address(addr).value = abase + offset[slot] + delta
+        self._tmp_rel = [(ctypes.c_uint64.from_address(addr), offset[slot] + delta) for addr, slot, delta in tmp_rel]
+        self._arena = arena if arena is not None else Arena()
+        if dev is not None:
+            self._arena.attach(self, top, dev)
         self.ext_rel = ext_rel
         tmp_ids = {id(t) for t in temps}
         self.keep = [k for k in rec.keep if not (isinstance(k, torch.Tensor) and (id(k) in tmp_ids or id(k) in {id(t) for t in ext}))]
         self.persistent = list(persistent)
+
+    arena = property(lambda self: self._arena.buf)
+
+    def _patch_arena(self, base):
+        for cell, off in self._tmp_rel:
+            cell.value = base + off
 
     def run(self, externals):
         """-> (fresh output Acts, persistent output Acts)"""
@@ -246,16 +270,17 @@ class FrameProgram:
 FRAME_PROGRAMS = [_os.environ.get("DSVC_NO_FRAME_PROGRAMS", "") == ""]
 
 
-def run_segment(cache, key, externals, fn, n_fresh=0):
+def run_segment(cache, key, externals, fn, arena=None):
     """Run one frame segment: fn(*externals) -> (fresh outputs [Act...], persistent outputs [Act...]).  First call: issued launch by
-    launch while recorded; afterwards one FrameProgram.run.  A segment holding an op without a scan-op form stays eager."""
+    launch while recorded; afterwards one FrameProgram.run.  A segment holding an op without a scan-op form stays eager.
+    `arena`: the Arena shared by the segments that run serially on this stream."""
     prog = cache.get(key) if (FRAME_PROGRAMS[0] and cache is not None) else False
     if prog is False or _rec() is not None:
         return fn(*externals)
     if prog is None:
         with ScanRecorder() as rec:
             fresh, persistent = fn(*externals)
-        cache[key] = False if rec.poisoned is not None else FrameProgram(rec, externals, fresh, persistent)
+        cache[key] = False if rec.poisoned is not None else FrameProgram(rec, externals, fresh, persistent, arena)
         return fresh, persistent
     return prog.run(externals)
 

@@ -174,6 +174,8 @@ class DeepSVC(nn.Module):
         if self.__dict__.get("_fp_seen") != fp:
             cache.clear()
             self.__dict__["_fp_seen"] = fp
+            # E1 / E2a / E2 / D1 / D2 run one after the other on the caller's stream and share one arena; DR runs beside D1 on the side stream
+            self.__dict__["_arenas"] = (ops.Arena(), ops.Arena())
         sig = lambda t: (tuple(t.buf.shape), t.c0, t.C, t.code) if isinstance(t, Act) else \
             (None if t is None else (tuple(t.shape), str(t.dtype), t.is_contiguous()))
         return cache, (str(ref.device), ops.RT.mode, ops.RT.compute, sig(ref)) + tuple(sig(t) for t in others)
@@ -207,15 +209,16 @@ class DeepSVC(nn.Module):
             self.res_codec.enc_gpu([ref, res, predict], ws_res)
             return [], []
 
-        ops.run_segment(cache, ("E1", key), [ref, cur], e1)
+        arena = self.__dict__.get("_arenas", (None, None))[0]
+        ops.run_segment(cache, ("E1", key), [ref, cur], e1, arena)
         # the mv streams are range-coded on a worker thread while the GPU runs prediction + the residual analysis
         mv_pending = self.mv_codec.enc_finish(ws_mv, defer=True)
-        _, (mv_coarse,) = ops.run_segment(cache, ("E2a", key), [], e2a)
+        _, (mv_coarse,) = ops.run_segment(cache, ("E2a", key), [], e2a, arena)
         # from here on nothing of the encoder touches the motion codec's scan workspace: the decoder's motion chain of this frame may
         # start on its own stream while the rest of the encoder still runs (decompress())
         done = self.__dict__["_mv_ws_free"] = torch.cuda.Event()
         done.record()
-        ops.run_segment(cache, ("E2", key), [ref, cur, sm_fea, mv_coarse] + opt, e2)
+        ops.run_segment(cache, ("E2", key), [ref, cur, sm_fea, mv_coarse] + opt, e2, arena)
         res_pending = self.res_codec.enc_finish(ws_res, defer=True)
         # both are dicts that join their coder thread on first access: a caller that forwards them to decompress()
         # without looking inside overlaps the residual range coding with the decoder's motion path
@@ -231,6 +234,7 @@ class DeepSVC(nn.Module):
         feat = self._feature_in(feature)
         cache, key = self._segments(ref, sm_fea, feat)
         opt = [] if feat is None else [feat]
+        arenas = self.__dict__.get("_arenas", (None, None))
         taps = self.__dict__.get("debug_taps")
         # The residual codec's decode chain (host range decoder + tiny scan kernels, 5 sync points) does not depend on
         # the motion path until reconstruction: it runs on a worker thread / side stream so its idle gaps overlap the
@@ -244,7 +248,7 @@ class DeepSVC(nn.Module):
             strings, shape = res_out_enc["strings"], res_out_enc["shape"]   # joins the encoder thread if still coding
             with torch.cuda.stream(side):
                 ws = self.res_codec.dec_chain(strings, shape, dev)
-                _, (out,) = ops.run_segment(cache, ("DR", key), [], lambda: ([], [self.res_codec._g_s(ws.y_hat)]))
+                _, (out,) = ops.run_segment(cache, ("DR", key), [], lambda: ([], [self.res_codec._g_s(ws.y_hat)]), arenas[1])
                 res_done.record(side)
             return out
 
@@ -287,13 +291,13 @@ class DeepSVC(nn.Module):
             clamp = lambda a: ops.eltwise(N.EW_CLAMP01, a)
             return [fea, clamp(recon), clamp(warped), clamp(predict)], []
 
-        _, (warped, warp_fea, predict, predict_fea) = ops.run_segment(cache, ("D1", key), [ref, sm_fea] + opt, d1)
+        _, (warped, warp_fea, predict, predict_fea) = ops.run_segment(cache, ("D1", key), [ref, sm_fea] + opt, d1, arenas[0])
         _stamp("D1 queued")
         res_coarse = res_future.result()
         _stamp("res chain done")
         main.wait_event(res_done)
         res_coarse.buf.record_stream(main)
-        (fea, recon_c, warped_c, predict_c), _ = ops.run_segment(cache, ("D2", key), [ref, warped, warp_fea, predict, predict_fea, res_coarse], d2)
+        (fea, recon_c, warped_c, predict_c), _ = ops.run_segment(cache, ("D2", key), [ref, warped, warp_fea, predict, predict_fea, res_coarse], d2, arenas[0])
         # `feature` is only ever handed back to the next frame: return it zero-copy in its storage layout/dtype
         return fea.nchw_view(), recon_c.nchw(), warped_c.nchw(), predict_c.nchw()
 
