@@ -19,6 +19,8 @@
 //     caller's dsvc_cdf_table (dsvc_cdf_build_lut); without one the decoder binary-searches.
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include <algorithm>
 #include "common.h"
@@ -118,6 +120,31 @@ extern "C" int dsvc_rans_encoder_create(void** enc) {
     return DSVC_OK;
 }
 
+// ---- which LUTs came from dsvc_cdf_build_lut ------------------------------------------------------------------------------
+// A table that carries a LUT skips the per-call row validation -- but only if THIS library built that LUT for THIS table: the
+// builder registers (lut pointer -> fingerprint of the table it validated); the coder looks it up (one mutex-free read of a small
+// array per call) and falls back to validating the rows when the pointer is unknown or the table behind it has changed.
+namespace {
+struct LutReg { const uint16_t* lut; uint64_t fp; };
+LutReg g_luts[64];
+std::atomic<int> g_nluts{0};
+std::mutex g_lut_mu;
+uint64_t table_fp(const dsvc_cdf_table* t) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix((uint64_t)(uintptr_t)t->cdf); mix((uint64_t)t->rows); mix((uint64_t)t->stride);
+    for (int r = 0; r < t->rows; ++r) { mix((uint64_t)(uint32_t)t->cdf_length[r]); mix((uint64_t)(uint32_t)t->cdf[(int64_t)r * t->stride + t->cdf_length[r] / 2]); }
+    return h;
+}
+bool lut_trusted(const dsvc_cdf_table* t) {
+    if (!t->lut) return false;
+    const int n = g_nluts.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (g_luts[i].lut == t->lut) return g_luts[i].fp == table_fp(t);
+    return false;
+}
+}  // namespace
+
 extern "C" void dsvc_rans_encoder_destroy(void* enc) { delete (Encoder*)enc; }
 
 extern "C" int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, const int32_t* indexes, int64_t n,
@@ -128,7 +155,7 @@ extern "C" int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, 
     e->nbytes = -1;
     // validation hoisted out of the symbol loop: the table once, the indexes in one vectorisable pass
     // (a table that carries a LUT was validated row by row when dsvc_cdf_build_lut made it)
-    if (!t->lut) { if (int rc = rows_valid(t, "rans_encode")) return rc; }
+    if (!lut_trusted(t)) { if (int rc = rows_valid(t, "rans_encode")) return rc; }
     for (int r = 0; r < t->rows; ++r)
         DSVC_REQUIRE(t->cdf_length[r] >= 2 && t->cdf_length[r] <= t->stride, "rans_encode: cdf_length[%d] invalid", r);
     {
@@ -221,6 +248,16 @@ extern "C" int64_t dsvc_rans_flush(void* enc, uint8_t* out, int64_t cap) {
 extern "C" int dsvc_cdf_build_lut(const dsvc_cdf_table* t, uint16_t* lut_out) {
     DSVC_REQUIRE(table_ok(t) && lut_out, "cdf_build_lut: bad argument");
     if (int rc = rows_valid(t, "cdf_build_lut")) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_lut_mu);
+        int n = g_nluts.load(std::memory_order_relaxed), slot = -1;
+        for (int i = 0; i < n; ++i) if (g_luts[i].lut == lut_out) slot = i;
+        if (slot < 0 && n < 64) slot = n;
+        if (slot >= 0) {                   // (a 65th live LUT is simply not trusted: its table is validated per call)
+            g_luts[slot] = LutReg{lut_out, table_fp(t)};
+            if (slot == n) g_nluts.store(n + 1, std::memory_order_release);
+        }
+    }
     for (int r = 0; r < t->rows; ++r) {
         const int32_t* row = t->cdf + (int64_t)r * t->stride;
         const int32_t len = t->cdf_length[r];
@@ -257,7 +294,7 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
         if (worst)
             for (int64_t i = 0; i < n; ++i)
                 DSVC_REQUIRE(indexes[i] >= 0 && indexes[i] < t->rows, "rans_decode: cdf index %d out of range at %lld", indexes[i], (long long)i);
-        if (!t->lut) { if (int rc = rows_valid(t, "rans_decode")) return rc; }
+        if (!lut_trusted(t)) { if (int rc = rows_valid(t, "rans_decode")) return rc; }
         for (int r = 0; r < t->rows; ++r)
             DSVC_REQUIRE(t->cdf_length[r] >= 2 && t->cdf_length[r] <= t->stride, "rans_decode: cdf_length[%d] invalid", r);
     }

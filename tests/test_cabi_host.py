@@ -189,6 +189,22 @@ def test_malformed_cdf_tables_are_rejected():
             ops.CdfTables(bad, lens, offs)
     with pytest.raises(RuntimeError):
         ops.CdfTables(good, np.array([4, 6], dtype=np.int32), offs)        # cdf_length beyond the row stride
+    # a LUT pointer alone buys no trust: only a LUT that dsvc_cdf_build_lut made for THIS table skips the per-call validation
+    bad = good.copy()
+    bad[0] = [0, 10, 10, 65536, 0]
+    forged_lut = np.zeros((2, 256), dtype=np.uint16)
+    forged = N.CdfTable(bad.ctypes.data, 2, 5, lens.ctypes.data, offs.ctypes.data, forged_lut.ctypes.data)
+    L = N.lib()
+    h = ctypes_void = __import__("ctypes").c_void_p()
+    assert L.dsvc_rans_encoder_create(__import__("ctypes").byref(h)) == 0
+    sym, idx = np.array([0, 1], dtype=np.int32), np.array([0, 1], dtype=np.int32)
+    assert L.dsvc_rans_encode_with_indexes(h, sym.ctypes.data, idx.ctypes.data, 2, __import__("ctypes").byref(forged)) < 0, "forged LUT was trusted"
+    L.dsvc_rans_encoder_destroy(h)
+    # ... and editing a table after its LUT was built revokes the trust
+    t2 = ops.CdfTables(good.copy(), lens, offs)
+    t2.cdf[0, 2] = 10                                  # now a zero-frequency symbol (also the fingerprinted mid entry)
+    with pytest.raises(RuntimeError):
+        ops.RansEncoder().encode_with_indexes(sym, idx, t2)
 
 
 def test_scan_op_ctypes_mirrors_match_the_header(tmp_path):
