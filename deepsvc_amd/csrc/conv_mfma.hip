@@ -50,6 +50,17 @@ extern "C" int dsvc_dbg_phase_read(unsigned long long* out8, int reset) {
 #define PROBE_FINISH
 #endif
 
+#ifdef DSVC_PP_CLOCK
+// Diagnostic build only (tools/pp_clock.py): in-kernel shader clock of the general kernel, as in conv3x3_pp.hip -- wave 0 of every
+// workgroup stamps s_memtime / s_memrealtime around its channel-chunk loop; [0] += d(memtime), [1] += d(memrealtime), [2] += 1.
+__device__ unsigned long long g_mfma_clock[3];
+extern "C" int dsvc_dbg_mfma_clock_read(unsigned long long* out3, int reset) {
+    if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_mfma_clock), sizeof(g_mfma_clock)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[3] = {0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_clock), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 namespace {
 using namespace dsvc_conv;
 
@@ -116,7 +127,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     // ---- weight prefetch: the packed weights of the NEXT staging step travel L2 -> registers while the MFMAs of the
     // current one run (a staging step is one L2 round trip of ~2.5 k clocks with nothing else to do in this workgroup:
     // 30 % of its time, tools/phase_probe.py).  WP = vectors per thread that fit the register budget of the variant.
-    constexpr int WP = (MT == 4 || sizeof(CT) == 4) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
+    // (fp32 mode too since round 3: its in-kernel clock is 2.38 GHz -- not power-limited -- so exposed staging latency is lost MFMA time)
+    // (not for fp32 with 128 output channels per group: 128 accumulator registers + the prefetch vectors spill)
+    constexpr int WP = (MT == 4 || (sizeof(CT) == 4 && NT == 4)) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
     uint4 wv[WP > 0 ? WP : 1];
     const rsrc_t rw = make_rsrc((const char*)p.w + (size_t)b * p.w_bs, p.w_bytes);
     const bool wfull = (ng + 1) * NTN <= p.Np;
@@ -171,8 +184,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float lo = h16_lo(u[k]), hi = h16_hi(u[k]);
-                        u[k] = pk_h16(fmaxf(lo, lo * sl), fmaxf(hi, hi * sl));
+                        if constexpr (sizeof(CT) == 4) {
+                            const float f = __builtin_bit_cast(float, u[k]);
+                            u[k] = __builtin_bit_cast(unsigned, fmaxf(f, f * sl));
+                        } else {
+                            const float lo = h16_lo(u[k]), hi = h16_hi(u[k]);
+                            u[k] = pk_h16(fmaxf(lo, lo * sl), fmaxf(hi, hi * sl));
+                        }
                     }
                     v = make_uint4(u[0], u[1], u[2], u[3]);
                 }
@@ -188,6 +206,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
 #endif
     PROBE_STAMP(t_begin)
+#ifdef DSVC_PP_CLOCK
+    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int ch = 0; ch < p.nchunks; ++ch) {
         PROBE_STAMP(t_a)
         int s = 0;
@@ -461,6 +482,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         }
     }
     PROBE_STAMP(t_epi)
+#ifdef DSVC_PP_CLOCK
+    if (tid == 0) {
+        const unsigned long long ck_t1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&g_mfma_clock[0], ck_t1 - ck_t0); atomicAdd(&g_mfma_clock[1], ck_r1 - ck_r0); atomicAdd(&g_mfma_clock[2], 1ull);
+    }
+#endif
 
     // ---- epilogue ----
     // MFMA C/D layout: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel).
@@ -602,6 +629,9 @@ int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, in
             return launch_cfg<CT, 2, 4, true, true>(st, p, ngroups, lds);
         }
         if (MT == 4) return launch_cfg<CT, 4, 2, true>(st, p, ngroups, lds);      // 16x32-pixel tiles: f16, vector staging, 64 output channels per group
+    }
+    if constexpr (sizeof(CT) == 4) {
+        if (fast && MT == 2 && NT == 2 && p.patchpf) return launch_cfg<CT, 2, 2, true, false, 6>(st, p, ngroups, lds);     // fp32: slab epilogue + patch prefetch
     }
     if (fast) return MT == 2 ? launch_nt<CT, 2, true>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, true>(st, p, NT, ngroups, lds);
     return MT == 2 ? launch_nt<CT, 2, false>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, false>(st, p, NT, ngroups, lds);
@@ -836,7 +866,7 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > budget) p.tapg = d->kw;
     if (lds_a + (size_t)p.tapg * NT * 32 * ROWB > 160 * 1024) p.tapg = 1;
     {   // the weight prefetch registers of the kernel variant (WP in conv_mfma_kernel) hold one whole staging step
-        const int wp = (MT == 4 || d->compute != DSVC_F16) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
+        const int wp = (MT == 4 || (d->compute == DSVC_F32 && NT == 4)) ? 0 : (NT == 1 ? 5 : NT == 2 ? 9 : NT == 3 ? 5 : 6);
         if (wp > 0 && (p.tapg * NT + 1) / 2 > wp) p.tapg = 2 * wp / NT;
     }
     const size_t lds_main = lds_a + (size_t)p.tapg * NT * 32 * ROWB;
@@ -851,7 +881,8 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     {   // patch prefetch variant: f16 storage everywhere, one staging batch (<= 6 vectors per thread) per chunk
         // (96 output channels: 256 registers with spills, 142 vs 129 us; with the k-step fragment pipeline to free registers 137 vs
         //  121 us for the tap-level pipeline without patch prefetch -- not taken)
-        p.patchpf = p.regepi && opt.patch_prefetch && MT == 2 && NT == 2 && same_type && PH * PW <= 6 * 64;
+        const bool f32_pf = d->compute == DSVC_F32 && fast && d->kh == 3 && d->kw == 3 && d->stride == 1 && !p.s2d;
+        p.patchpf = (p.regepi || f32_pf) && opt.patch_prefetch && MT == 2 && NT == 2 && same_type && PH * PW <= 6 * 64;
     }
     const size_t lds_epi = p.regepi ? 0 : (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;

@@ -242,8 +242,8 @@ class FrameProgram:
         if dev is not None:
             self._arena.attach(self, top, dev)
         self.ext_rel = ext_rel
-        tmp_ids = {id(t) for t in temps}
-        self.keep = [k for k in rec.keep if not (isinstance(k, torch.Tensor) and (id(k) in tmp_ids or id(k) in {id(t) for t in ext}))]
+        drop = {id(t) for t in temps} | {id(t) for t in ext}         # the arena replaces the former, the caller owns the latter
+        self.keep = [k for k in rec.keep if not (isinstance(k, torch.Tensor) and id(k) in drop)]
         self.persistent = list(persistent)
 
     arena = property(lambda self: self._arena.buf)

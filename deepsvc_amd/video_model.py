@@ -258,10 +258,9 @@ class DeepSVC(nn.Module):
         # this frame has just been queued (test_video.py:342,349 calls them back to back) part of its latency hides under the encoder's
         # remaining kernels (tiny kernels only get CU slots at the boundaries of the large ones, so the chain advances one launch per
         # large kernel: measured 7.9 ms for the chain beside E2 against ~4.5 ms alone).
-        import os
         mvs = main if not MV_STREAM[0] else self.__dict__.setdefault("_mv_streams", {}).get(str(dev))
         if mvs is None:
-            mvs = self.__dict__["_mv_streams"][str(dev)] = torch.cuda.Stream(dev, priority=int(os.environ.get("DSVC_MV_STREAM_PRIO", "-1")))
+            mvs = self.__dict__["_mv_streams"][str(dev)] = torch.cuda.Stream(dev, priority=-1)
         free = self.__dict__.get("_mv_ws_free")
         with torch.cuda.stream(mvs):
             if free is not None:

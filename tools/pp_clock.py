@@ -44,3 +44,39 @@ for name, kw in CASES:
     print(f"{name:28s} {us:7.1f} us per launch, tile loop {loop_us:6.1f} us, in-kernel clock {ghz:.3f} GHz "
           f"-> {154.0e9 / us / 1e6:.1f} TFLOP/s = {154.0e9 / us / 1e6 / (2500.0 * ghz / 2.4):.2f} of the MFMA rate available at that clock "
           f"({2500.0 * ghz / 2.4:.0f} TFLOP/s)", flush=True)
+
+# ---- the general kernel (csrc/conv_mfma.hip): fp32 mode's dominant conv and the f16 shapes that do not fit the ping-pong kernel ----
+def generic(name, mode, cin, cout, k, Hh, Ww, flop):
+    ops.set_precision(mode)
+    dt = torch.float32 if mode == "fp32" else torch.float16
+    xs = [ops.Act(torch.randn((1, Hh, Ww, c), device=dev).to(dt)) for c in cin]
+    conv = Conv2d(sum(cin), cout, k, 1, k // 2).to(dev)
+    out = ops.new_act(1, Hh, Ww, cout, dt, dev)
+    t0 = time.time()
+    while time.time() - t0 < 2.2:
+        for _ in range(10):
+            conv.run(xs, out, out_dtype=dt)
+        torch.cuda.synchronize()
+    L.dsvc_dbg_mfma_clock_read(buf, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 40
+    for _ in range(n):
+        conv.run(xs, out, out_dtype=dt)
+    e1.record(); torch.cuda.synchronize()
+    L.dsvc_dbg_mfma_clock_read(buf, 1)
+    dtk, dr, cnt = list(buf)
+    us = e0.elapsed_time(e1) / n * 1e3
+    ghz = dtk / max(dr, 1) * 0.1
+    peak = (157.3 if mode == "fp32" else 2500.0) * ghz / 2.4
+    print(f"{name:34s} {us:8.1f} us per launch, in-kernel clock {ghz:.3f} GHz -> {flop / us / 1e6:7.1f} TFLOP/s = {flop / us / 1e6 / peak:.2f} of the "
+          f"{peak:.0f} TFLOP/s available at that clock ({'fp32' if mode == 'fp32' else 'f16'} MFMA)", flush=True)
+
+
+F = lambda cin, cout, k, Hh, Ww: 2.0 * Hh * Ww * cin * cout * k * k
+generic("fp32 3x3 64->64 @1088x1920", "fp32", [64], 64, 3, H, W, F(64, 64, 3, H, W))
+generic("f16 3x3 64+64->64 @1088x1920", "f16", [64, 64], 64, 3, H, W, F(128, 64, 3, H, W))
+generic("f16 3x3 96->96 @544x960", "f16", [96], 96, 3, H // 2, W // 2, F(96, 96, 3, H // 2, W // 2))
+generic("f16 3x3 128->128 @272x480", "f16", [128], 128, 3, H // 4, W // 4, F(128, 128, 3, H // 4, W // 4))
+generic("f16 7x7 64->32 @1088x1920", "f16", [64], 32, 7, H, W, F(64, 32, 7, H, W))
+ops.set_precision("fp32")
