@@ -30,6 +30,7 @@ struct ConvParams {
     int tiles_x, tiles_y, tapg;
     unsigned out_bytes, res1_bytes, res2_bytes;   // extents for the buffer resources of the vector epilogue
     int epi_vec;                                   // 1: epilogue may use 4-channel vector buffer ops everywhere
+    int epi_f32;                                   // 1: output and every residual are fp32 (fp32 mode): the vector epilogue issues only the fp32 instructions
     int s2d;                                       // 1: inputs are a space-to-depth view of a (2H x 2W) image (dsvc.h)
     const void* post_w; const float* post_bias;    // fused trailing 1x1 conv (dsvc.h: post_weight), conv3x3_pp only
     int b_inner;                                   // see ConvSeg::bs_lo (dense batch: INT_MAX)
@@ -173,7 +174,9 @@ __device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* 
 
 
 // ---- straight-line vector epilogue: NPL pixels of a wave-private slab, 4 channels per lane -------------------------
-template <int ACT, bool HAS_RES, int GPP, int EPLD, int NPL>
+// ALLF32: output and residuals are known to be fp32 -- the loads / stores of the other element type are not even issued (a masked
+// buffer instruction still costs its issue slot: ~150-250 cycles each beside the other workgroup's MFMA stream, tools/phase_probe_fp32.py)
+template <int ACT, bool HAS_RES, int GPP, int EPLD, int NPL, bool ALLF32 = false>
 __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc& R, const float* slab, int lane, int b,
                                              int oy_base, int ox0, int co0, int cpass) {
     const int g = lane % GPP;
@@ -203,9 +206,12 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
         if constexpr (HAS_RES) {
             const unsigned e1 = spix * p.res1_ld + lane_1, e2 = spix * p.res2_ld + lane_2;
             const v4u_t f1 = __builtin_amdgcn_raw_buffer_load_b128(R.r1, (ok && R.r1_f32) ? e1 * 4 : OOB, 0, 0);
-            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_h16) ? e1 * 2 : OOB, 0, 0);
             const v4u_t f2 = __builtin_amdgcn_raw_buffer_load_b128(R.r2, (ok && R.r2_f32) ? e2 * 4 : OOB, 0, 0);
-            const v2u_t h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_h16) ? e2 * 2 : OOB, 0, 0);
+            v2u_t h1 = {0u, 0u}, h2 = {0u, 0u};
+            if constexpr (!ALLF32) {
+                h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_h16) ? e1 * 2 : OOB, 0, 0);
+                h2 = __builtin_amdgcn_raw_buffer_load_b64(R.r2, (ok && R.r2_h16) ? e2 * 2 : OOB, 0, 0);
+            }
             // NB: lanes are copied to scalars first -- __builtin_bit_cast applied directly to an ext-vector element
             // (f1.y) is compiled as a cast of element 0 by hipcc 7.2.
             const unsigned a1[4] = {f1.x, f1.y, f1.z, f1.w}, a2[4] = {f2.x, f2.y, f2.z, f2.w};
@@ -229,7 +235,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
         ob.x = pk_h16(v[0], v[1]);
         ob.y = pk_h16(v[2], v[3]);
         __builtin_amdgcn_raw_buffer_store_b128(of, R.out, (ok && R.out_f32) ? eo * 4 : OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(ob, R.out, (ok && !R.out_f32) ? eo * 2 : OOB, 0, 0);
+        if constexpr (!ALLF32) __builtin_amdgcn_raw_buffer_store_b64(ob, R.out, (ok && !R.out_f32) ? eo * 2 : OOB, 0, 0);
     }
 }
 
@@ -240,6 +246,8 @@ __device__ __forceinline__ void run_epilogue(const ConvParams& p, const EpiRsrc&
 #define DSVC_EPI_CASE(A)                                                                                            \
     case A:                                                                                                         \
         if (!p.epi_vec) epilogue_pass<A, GPP, EPLD>(p, slab, lane, NPL, b, oy_base, ox0, co0, cpass);               \
+        else if (p.epi_f32 && (p.res1 || p.res2)) epilogue_vec<A, true, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
+        else if (p.epi_f32) epilogue_vec<A, false, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
         else if (p.res1 || p.res2) epilogue_vec<A, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
         else epilogue_vec<A, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);                 \
         break;
@@ -251,6 +259,8 @@ __device__ __forceinline__ void run_epilogue(const ConvParams& p, const EpiRsrc&
         DSVC_EPI_CASE(DSVC_ACT_HALF_TANH)
         default:
             if (!p.epi_vec) epilogue_pass<DSVC_ACT_NONE, GPP, EPLD>(p, slab, lane, NPL, b, oy_base, ox0, co0, cpass);
+            else if (p.epi_f32 && (p.res1 || p.res2)) epilogue_vec<DSVC_ACT_NONE, true, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+            else if (p.epi_f32) epilogue_vec<DSVC_ACT_NONE, false, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
             else if (p.res1 || p.res2) epilogue_vec<DSVC_ACT_NONE, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
             else epilogue_vec<DSVC_ACT_NONE, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
             break;

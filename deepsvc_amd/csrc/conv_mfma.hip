@@ -793,6 +793,7 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         DSVC_REQUIRE(oe < 0x7FFFFFF0ll && r1e < 0x7FFFFFF0ll && r2e < 0x7FFFFFF0ll, "conv2d: output/residual tensor above 2 GiB");
         p.out_bytes = (unsigned)oe; p.res1_bytes = (unsigned)r1e; p.res2_bytes = (unsigned)r2e;
         p.epi_vec = d->shuffle == 1 && (d->Cout % 4) == 0 && p.out_vec && (!d->res1 || p.res1_vec) && (!d->res2 || p.res2_vec);
+        p.epi_f32 = g_dsvc_opt.epi_f32 && d->out_dtype == DSVC_F32 && (!d->res1 || d->res1_dtype == DSVC_F32) && (!d->res2 || d->res2_dtype == DSVC_F32);
     }
     bool fast = true;
     for (int s = 0; s < d->nseg; ++s)

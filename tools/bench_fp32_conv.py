@@ -23,7 +23,7 @@ def run(name, cin, cout, k, Hh, Ww, kw=None, n=10):
     if kw.pop("res", False):
         kw["res1"] = ops.Act(torch.randn((1, Hh, Ww, cout), device=dev).to(DT))
     res = {}
-    for pf in (0, 1, 0, 1):
+    for pf in (0, 1, 0, 1, 1, 0):
         ops.set_option(OPT, pf)
         for _ in range(2):
             conv.run(xs, out, out_dtype=DT, **kw)
@@ -39,6 +39,7 @@ def run(name, cin, cout, k, Hh, Ww, kw=None, n=10):
             assert torch.equal(ref, out.buf), f"{name}: patch prefetch changed the fp32 result"
     flop = 2.0 * Hh * Ww * sum(cin) * cout * k * k
     best = {p: min(v) for p, v in res.items()}
+    print("      raw us:", {k: [round(x, 1) for x in v] for k, v in res.items()})
     peak = 157.3 if MODE == "fp32" else 2500.0
     print(f"{name:36s} {OPT}=0 {best[0]:8.1f} us ({flop / best[0] / 1e6:6.1f} TFLOP/s)   {OPT}=1 {best[1]:8.1f} us ({flop / best[1] / 1e6:6.1f} TFLOP/s = "
           f"{flop / best[1] / 1e6 / peak:.2f} of the {MODE} MFMA peak)", flush=True)
