@@ -174,30 +174,6 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     const rsrc_t rr1 = make_rsrc(HAS_R1 ? p.res1 : p.out, HAS_R1 ? p.res1_bytes : p.out_bytes);
     const rsrc_t rr2 = make_rsrc(HAS_R2 ? p.res2 : p.out, HAS_R2 ? p.res2_bytes : p.out_bytes);
 
-    // ---- weights: staged once (rows are [chunk][tap][Np == NTN] x 64 B in global memory) ----
-    {
-        const int nrows = NCH * 9 * NTN, q = tid & 3;
-        for (int base = tid >> 2; base < nrows; base += 128 * 6) {
-            uint4 v[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int row = base + 128 * j;
-                v[j] = make_uint4(0, 0, 0, 0);
-                if (row < nrows) v[j] = *(const uint4*)((const char*)p.w + (size_t)row * 64 + q * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (base + 128 * j < nrows) *(uint4*)(lds_w + perm_row(base + 128 * j) * ROWB + q * 16) = v[j];
-        }
-    }
-
-    if (tid < NTN) lds_bias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
-    if constexpr (POST) {
-        if (tid < NTN) lds_bias[NTN + tid] = (p.post_bias && tid < p.Cout) ? p.post_bias[tid] : 0.f;
-        const int q4 = tid & 3;                     // packed 1x1 weights: [chunk][tap 0][Np == NTN] rows of 64 B
-        for (int row = tid >> 2; row < NT * NTN; row += 128)
-            *(uint4*)(lds_w3 + perm_row(row) * ROWB + q4 * 16) = *(const uint4*)((const char*)p.post_w + (size_t)row * 64 + q4 * 16);
-    }
     const int H = p.H, W = p.W, tiles_x = p.tiles_x, tiles_y = p.tiles_y;
     // Address arithmetic is kept off the vector ALU as far as possible (it runs beside the other group's MFMA phase):
     // tile coordinates are wave-uniform and computed once per iteration; per-thread patch offsets are loop-invariant;
@@ -410,7 +386,42 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     uint4 pf0[PP_PFV], pf1[PP_PFV];
     TileOrg cur = tile_origin(min(tile_of(0), ntiles - 1)), nxt = tile_origin(min(tile_of(1), ntiles - 1));
     load_chunk(cur, 0, pf0);
-    store_chunk(pf0);
+    // ---- weights: staged once per workgroup (rows are [chunk][tap][Np == NTN] x 64 B in global memory).  All loads of a thread are issued
+    // back to back behind the first patch loads (bounds-checked buffer loads, masked by the offset: conditional loads had been compiled to
+    // one branch + L2 round trip each), so the prologue costs ONE memory round trip instead of ~ten ----
+    {
+        constexpr int nrows = NCH * 9 * NTN, NWV = (nrows + 127) / 128;
+        constexpr int nrows3 = POST ? NT * NTN : 0, NWV3 = (nrows3 + 127) / 128;
+        const int q4 = tid & 3;
+        const rsrc_t rw = make_rsrc(p.w, (unsigned)nrows * 64u);
+        const rsrc_t rw3 = make_rsrc(POST ? p.post_w : p.w, (unsigned)(POST ? nrows3 : nrows) * 64u);
+        uint4 wv[NWV], wv3[NWV3 > 0 ? NWV3 : 1];
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const unsigned row = (unsigned)(tid >> 2) + 128u * j;
+            wv[j] = buf_load16(rw, (row * 64u + q4 * 16u) | (row < (unsigned)nrows ? 0u : OOB));
+        }
+#pragma unroll
+        for (int j = 0; j < NWV3; ++j) {
+            const unsigned row = (unsigned)(tid >> 2) + 128u * j;
+            wv3[j] = buf_load16(rw3, (row * 64u + q4 * 16u) | (row < (unsigned)nrows3 ? 0u : OOB));
+        }
+        if (tid < NTN) lds_bias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
+        if constexpr (POST) {
+            if (tid < NTN) lds_bias[NTN + tid] = (p.post_bias && tid < p.Cout) ? p.post_bias[tid] : 0.f;
+        }
+        store_chunk(pf0);                      // the patch loads were issued first and return first
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int row = (tid >> 2) + 128 * j;
+            if (row < nrows) *(uint4*)(lds_w + perm_row(row) * ROWB + q4 * 16) = wv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NWV3; ++j) {
+            const int row = (tid >> 2) + 128 * j;
+            if (row < nrows3) *(uint4*)(lds_w3 + perm_row(row) * ROWB + q4 * 16) = wv3[j];
+        }
+    }
     if constexpr (NCH == 2) load_chunk(cur, 1, pf1);
     if constexpr (!PF0S1) load_chunk(nxt, 0, pf0);
     if constexpr (HAS_R1 && !(RES_IN_S1 && NCH == 2)) load_res(cur, tile_of(0) < ntiles, 0, (PP_RES_SPLIT && NCH == 2) ? 1 : MTW);
