@@ -146,3 +146,29 @@ def test_real_bpp_close_to_estimate(oracle_w0):
     real = (strings_nbytes(mv) + strings_nbytes(res)) * 8 / (64 * 64)
     est = float(out[7])
     assert 0.5 * est < real < 1.5 * est
+
+
+def test_oracle_reproduces_reference_bytes_at_256x1024():
+    """The wide fixture (tests/golden/make_golden_full.py: the REFERENCE run on three chained P-frames of 256x1024, the smallest picture
+    that takes the large-image GPU kernels): the oracle's four byte strings per frame are the reference's, and its reconstruction chain
+    stays on the reference's.  This pins the oracle at a non-square size with feature carry-over (video_model.py:137-167)."""
+    import os
+    from oracle.codec import DeepSVCOracle
+    from parity_util import check_golden_full
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deepsvc_ref_256x1024.npz"))
+    o = DeepSVCOracle(synth.make_model("W0").state_dict())
+    o.update()
+    frames = synth.make_frames(256, 1024, 4)
+    ref, feat = frames[0], None
+    for t in (1, 2, 3):
+        sm = synth.make_sm_fea(256, 1024, t)
+        mv, res = o.compress(ref, frames[t], sm, feat)
+        for nm, enc in (("mv", mv), ("res", res)):
+            assert enc["strings"][0][0] == g[f"s256x1024/f{t}/enc/{nm}_y"].tobytes(), (t, nm, "y")
+            assert enc["strings"][1][0] == g[f"s256x1024/f{t}/enc/{nm}_z"].tobytes(), (t, nm, "z")
+            assert tuple(enc["shape"]) == tuple(g[f"s256x1024/f{t}/enc/{nm}_shape"])
+        feat, recon, warped, predict = o.decompress(ref, mv, res, sm, feat)
+        check_golden_full(g, f"s256x1024/f{t}/dec/recon", recon, 1e-5)
+        check_golden_full(g, f"s256x1024/f{t}/dec/predict", predict, 1e-5)
+        ref = recon
+    check_golden_full(g, "s256x1024/f3/dec/feature", feat, 1e-5)
