@@ -5,7 +5,9 @@
 The shared library lands in deepsvc_amd/lib/ (git-ignored; it travels to the GPU box with the
 repo snapshot).  hipcc cross-compiles without a GPU.
 """
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -16,6 +18,13 @@ LIB = os.path.join(LIB_DIR, "libdsvc.so")
 SOURCES = ["conv_mfma.hip", "conv3x3_ws.hip", "conv3x3_pp.hip", "conv1x1.hip", "pointwise.hip", "msssim.hip", "entropy.hip", "rans_host.cpp", "host_misc.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "dsvc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("DSVC_BUILD_DEFINES", "").split()
+
+
+# kernel -> scratch bytes per lane tolerated by the build check below
+SCRATCH_ALLOWED = {
+    # opt-in variant (option "ws_waves4": one wave per SIMD with a 4 x 2 register tile, 256 VGPRs): three dwords spilled around its epilogue
+    "_ZN12_GLOBAL__N_117conv3x3_ws_kernelILi2ELb1ELb0ELi4EEEvN9dsvc_conv10ConvParamsEi": 16,
+}
 
 
 def _hipcc():
@@ -30,6 +39,30 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _resource_usage(remarks):
+    """hipcc -Rpass-analysis=kernel-resource-usage output -> {kernel: {vgprs, agprs, sgprs, scratch, lds, occupancy}}."""
+    out = {}
+    for blk in remarks.split("Function Name: ")[1:]:
+        name = blk.split()[0]
+        num = lambda pat: int(m.group(1)) if (m := re.search(pat, blk)) else -1
+        out[name] = {"vgprs": num(r" VGPRs: (\d+)"), "agprs": num(r"AGPRs: (\d+)"), "sgprs": num(r"SGPRs: (\d+)"),
+                     "scratch": num(r"ScratchSize \[bytes/lane\]: (\d+)"), "lds": num(r"LDS Size \[bytes/block\]: (\d+)"),
+                     "occupancy": num(r"Occupancy \[waves/SIMD\]: (\d+)")}
+    return out
+
+
+def resource_usage(variant=None):
+    """Per-kernel register / scratch / LDS use of the last build (lib/obj*/ *.usage.json, written while compiling)."""
+    obj_dir = os.path.join(LIB_DIR, "obj" if variant is None else f"obj_{variant}")
+    out = {}
+    for src in SOURCES:
+        up = os.path.join(obj_dir, os.path.splitext(src)[0] + ".usage.json")
+        if os.path.exists(up):
+            with open(up) as f:
+                out.update(json.load(f))
+    return out
 
 
 def build(force=False, verbose=False, variant=None, defines=()):
@@ -49,16 +82,24 @@ def build(force=False, verbose=False, variant=None, defines=()):
         op = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+            cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            procs.append((src, op, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
             relink = True
-    for src, pr in procs:
+    for src, op, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
-    if relink:
+        if src.endswith(".hip"):
+            with open(os.path.splitext(op)[0] + ".usage.json", "w") as f:
+                json.dump(_resource_usage(out.decode(errors="replace")), f, indent=0, sort_keys=True)
+    # No kernel of this library may touch scratch memory: a kernel that does has lost an array or its accumulators to the stack (once: the
+    # generic conv's slab-epilogue variants, 3x slower, unnoticed by every parity test).  DSVC_ALLOW_SCRATCH=1 turns the check off.
+    spilled = {k: v["scratch"] for k, v in resource_usage(variant).items() if v["scratch"] > SCRATCH_ALLOWED.get(k, 0)}
+    if spilled and not os.environ.get("DSVC_ALLOW_SCRATCH"):
+        raise RuntimeError("kernels using scratch memory (bytes per lane): " + ", ".join(f"{k}: {v}" for k, v in sorted(spilled.items())))
+    if relink or _stale(LIB, objs):      # (objects newer than the library: an earlier run compiled them and then stopped)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -69,12 +69,21 @@ __device__ __forceinline__ void lds_barrier() {
 struct EpiRsrc {      // one descriptor per operand (an absent residual borrows the output's; its offsets are all OOB)
     rsrc_t out, r1, r2;
     bool out_f32, r1_f32, r1_h16, r2_f32, r2_h16;
+    // the epilogue's view of output / first residual / bias: the launch's, or -- per-item placement (dsvc.h: out_bstride) -- this item's,
+    // with bias_bs = 0 and batch index 0.  Kept here as three scalars: a modified COPY of ConvParams lands on the stack (256 B of scratch
+    // per thread plus the spills it provokes -- the slab-epilogue variants ran 3x slower for a while, tools/bench_subpel.py).
+    void* outp; const void* r1p; const float* bias; int bias_bs;
 };
-__device__ __forceinline__ EpiRsrc make_epi_rsrc(const ConvParams& p) {
+__device__ __forceinline__ EpiRsrc make_epi_rsrc(const ConvParams& p, int item = 0) {
     EpiRsrc R;
-    R.out = make_rsrc(p.out, p.out_bytes);
-    R.r1 = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? p.res1_bytes : p.out_bytes);
-    R.r2 = make_rsrc(p.res2 ? p.res2 : p.out, p.res2 ? p.res2_bytes : p.out_bytes);
+    const bool placed = p.out_bs != 0;
+    R.outp = placed ? (void*)((char*)p.out + (size_t)item * p.out_bs) : p.out;
+    R.r1p = (placed && p.res1) ? (const void*)((const char*)p.res1 + (size_t)item * p.res1_bs) : p.res1;
+    R.bias = (placed && p.bias) ? p.bias + (size_t)item * p.bias_bs : p.bias;
+    R.bias_bs = placed ? 0 : p.bias_bs;
+    R.out = make_rsrc(R.outp, p.out_bytes);
+    R.r1 = make_rsrc(p.res1 ? R.r1p : R.outp, p.res1 ? p.res1_bytes : p.out_bytes);
+    R.r2 = make_rsrc(p.res2 ? p.res2 : R.outp, p.res2 ? p.res2_bytes : p.out_bytes);
     R.out_f32 = p.out_dtype == DSVC_F32;
     R.r1_f32 = p.res1 && p.res1_dtype == DSVC_F32; R.r1_h16 = p.res1 && p.res1_dtype == DSVC_F16;
     R.r2_f32 = p.res2 && p.res2_dtype == DSVC_F32; R.r2_h16 = p.res2 && p.res2_dtype == DSVC_F16;
@@ -112,7 +121,7 @@ __device__ __forceinline__ void load4(const void* base, int dtype, int vec, int6
 }
 
 template <int ACT, int GPP, int EPLD>
-__device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* slab, int lane, int npl, int b, int oy_base,
+__device__ __forceinline__ void epilogue_pass(const ConvParams& p, const EpiRsrc& R, const float* slab, int lane, int npl, int b, int oy_base,
                                               int ox0, int co0, int cpass) {
     const int g = lane % GPP;
     const int co = co0 + g * 4;
@@ -121,7 +130,7 @@ __device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* 
     float bias[4] = {0.f, 0.f, 0.f, 0.f}, gate[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (p.bias && j < nv) bias[j] = p.bias[b * p.bias_bs + co + j];
+        if (R.bias && j < nv) bias[j] = R.bias[b * R.bias_bs + co + j];
         if (p.res1_scale && j < nv) gate[j] = p.res1_scale[(int64_t)b * p.Cout + co + j];
     }
     for (int pl = lane / GPP; pl < npl; pl += 64 / GPP) {
@@ -134,7 +143,7 @@ __device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* 
         if (p.shuffle == 1) {
             if (p.res1) {
                 float r[4];
-                load4(p.res1, p.res1_dtype, p.res1_vec, opix * p.res1_ld + co, nv, r);
+                load4(R.r1p, p.res1_dtype, p.res1_vec, opix * p.res1_ld + co, nv, r);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += gate[j] * r[j];
             }
@@ -147,17 +156,17 @@ __device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* 
             const int64_t oo = opix * p.out_ld + co;
             if (p.out_vec && nv == 4) {
                 if (p.out_dtype == DSVC_F32) {
-                    *(float4*)((float*)p.out + oo) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)((float*)R.outp + oo) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     uint2 u;
                     u.x = pk_h16(v[0], v[1]);
                     u.y = pk_h16(v[2], v[3]);
-                    *(uint2*)((unsigned short*)p.out + oo) = u;
+                    *(uint2*)((unsigned short*)R.outp + oo) = u;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j < nv) store_elem(p.out, p.out_dtype, oo + j, v[j]);
+                    if (j < nv) store_elem(R.outp, p.out_dtype, oo + j, v[j]);
             }
         } else {  // PixelShuffle(2): conv channel co+j = cq*4 + dy*2 + dx  (co % 4 == 0, Cout % 4 == 0)
             const int cq = co >> 2;
@@ -165,8 +174,8 @@ __device__ __forceinline__ void epilogue_pass(const ConvParams& p, const float* 
             for (int j = 0; j < 4; ++j) {
                 const int64_t spix = ((int64_t)b * (2 * p.Ho) + 2 * oy + (j >> 1)) * (2 * p.Wo) + 2 * ox + (j & 1);
                 float o = v[j];
-                if (p.res1) o += load_elem(p.res1, p.res1_dtype, spix * p.res1_ld + cq);
-                store_elem(p.out, p.out_dtype, spix * p.out_ld + cq, o);
+                if (p.res1) o += load_elem(R.r1p, p.res1_dtype, spix * p.res1_ld + cq);
+                store_elem(R.outp, p.out_dtype, spix * p.out_ld + cq, o);
             }
         }
     }
@@ -186,7 +195,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
     if (lane_ok) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (p.bias) bias[j] = p.bias[b * p.bias_bs + co + j];
+            if (R.bias) bias[j] = R.bias[b * R.bias_bs + co + j];
             if (p.res1_scale) gate[j] = p.res1_scale[(int64_t)b * p.Cout + co + j];
         }
     }
@@ -239,17 +248,102 @@ __device__ __forceinline__ void epilogue_vec(const ConvParams& p, const EpiRsrc&
     }
 }
 
-// one epilogue pass: vector path (straight-line, buffer ops) when the host proved alignment, else the general path
-template <int GPP, int EPLD, int NPL>
+// ---- the same for PixelShuffle(2) outputs (subpel convs: image_model.py:25-27, modules.py:127-131) -------------------------------
+// conv channel co = 4*cq + 2*dy + dx lands on output pixel (2*oy + dy, 2*ox + dx), channel cq.  Lane g of a pixel's GPP lanes takes the
+// sub-pixel s = g & 3 and the FOUR conv channels 16*(g >> 2) + 4*j + s (j = 0..3) of the staged pass: four consecutive output channels of
+// one output pixel, i.e. one 8-byte (f16) / 16-byte (fp32) vector instead of four scattered elements (the element-wise path ran the
+// 1088x1920 subpel convs at 0.05-0.07 of the MFMA peak: tools/conv_census.py).  Slab reads are 4 x ds_read_b32, conflict-free at the
+// EPLD = 68 pitch.  Host guarantees: Cout % 16 == 0, no gate / second residual, vector-aligned output and residual.
+template <int ACT, bool HAS_RES, int GPP, int EPLD, int NPL>
+__device__ __forceinline__ void epilogue_vec_shuffle(const ConvParams& p, const EpiRsrc& R, const float* slab, int lane, int b,
+                                                     int oy_base, int ox0, int co0, int cpass) {
+    const int g = lane % GPP, sub = g & 3, cqg = g >> 2;
+    const int cl = 16 * cqg + sub;                          // first conv channel of this lane inside the pass
+    const bool lane_ok = 16 * cqg < cpass && co0 + 16 * cqg < p.Cout;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane_ok && R.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = R.bias[b * R.bias_bs + co0 + cl + 4 * j];
+    }
+    constexpr int STEP = 64 / GPP;
+    const int lp = lane / GPP;
+    const int Wo2 = 2 * p.Wo;
+    const unsigned lpix = (unsigned)((sub >> 1) * Wo2 + 2 * lp + (sub & 1));      // this lane's output pixel relative to the iteration's
+    const unsigned cq = (unsigned)((co0 >> 2) + 4 * cqg);
+    const unsigned lane_o = lpix * p.out_ld + cq, lane_1 = lpix * p.res1_ld + cq;
+#pragma unroll 2
+    for (int it = 0; it < NPL / STEP; ++it) {
+        const int oy = oy_base + ((it * STEP) >> 5), xs = ox0 + ((it * STEP) & 31);   // scalars
+        const bool ok = lane_ok && oy < p.Ho && xs + lp < p.Wo;
+        const unsigned spix = ((unsigned)b * (2 * p.Ho) + 2 * oy) * Wo2 + 2 * xs;       // scalar
+        const float* sl = slab + (lp + it * STEP) * EPLD + cl;
+        float v[4] = {act_t<ACT>(sl[0] + bias[0], p.slope), act_t<ACT>(sl[4] + bias[1], p.slope),
+                      act_t<ACT>(sl[8] + bias[2], p.slope), act_t<ACT>(sl[12] + bias[3], p.slope)};
+        if constexpr (HAS_RES) {
+            const unsigned e1 = spix * p.res1_ld + lane_1;
+            const v4u_t f1 = __builtin_amdgcn_raw_buffer_load_b128(R.r1, (ok && R.r1_f32) ? e1 * 4 : OOB, 0, 0);
+            const v2u_t h1 = __builtin_amdgcn_raw_buffer_load_b64(R.r1, (ok && R.r1_h16) ? e1 * 2 : OOB, 0, 0);
+            const unsigned a1[4] = {f1.x, f1.y, f1.z, f1.w};
+            const unsigned h1x = h1.x, h1y = h1.y;
+            const float b1[4] = {h16_lo(h1x), h16_hi(h1x), h16_lo(h1y), h16_hi(h1y)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += __builtin_bit_cast(float, a1[j]) + b1[j];
+        }
+        const unsigned eo = spix * p.out_ld + lane_o;
+        v4u_t of;
+        of.x = __builtin_bit_cast(unsigned, v[0]); of.y = __builtin_bit_cast(unsigned, v[1]);
+        of.z = __builtin_bit_cast(unsigned, v[2]); of.w = __builtin_bit_cast(unsigned, v[3]);
+        v2u_t ob;
+        ob.x = pk_h16(v[0], v[1]);
+        ob.y = pk_h16(v[2], v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(of, R.out, (ok && R.out_f32) ? eo * 4 : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(ob, R.out, (ok && !R.out_f32) ? eo * 2 : OOB, 0, 0);
+    }
+}
+
+// one epilogue pass: vector path (straight-line, buffer ops) when the host proved alignment, else the general path.
+// F32K: the caller is an fp32-compute kernel -- only those instantiate the all-fp32 variants; SHUF: the caller can be launched with
+// PixelShuffle(2) (the generic kernel only).  Every variant is inlined into its caller, and the slab-epilogue kernels sit at the
+// register limit: offering the fp32-only variants to the f16 kernels as well made conv3x3_ws spill and pushed the generic kernel's
+// accumulators to scratch (build.py now refuses a library with scratch use).
+template <int GPP, int EPLD, int NPL, bool F32K = false, bool SHUF = false>
 __device__ __forceinline__ void run_epilogue(const ConvParams& p, const EpiRsrc& R, const float* slab, int lane, int b,
                                              int oy_base, int ox0, int co0, int cpass) {
+    if constexpr (SHUF) {
+        if (p.epi_vec && p.shuffle == 2) {      // subpel output (host: only with activation none / ReLU / LeakyReLU)
+            const bool res = p.res1 != nullptr;
+            if (p.act == DSVC_ACT_RELU) {
+                if (res) epilogue_vec_shuffle<DSVC_ACT_RELU, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+                else epilogue_vec_shuffle<DSVC_ACT_RELU, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+            } else if (p.act == DSVC_ACT_LRELU) {
+                if (res) epilogue_vec_shuffle<DSVC_ACT_LRELU, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+                else epilogue_vec_shuffle<DSVC_ACT_LRELU, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+            } else {
+                if (res) epilogue_vec_shuffle<DSVC_ACT_NONE, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+                else epilogue_vec_shuffle<DSVC_ACT_NONE, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
+            }
+            return;
+        }
+    }
+    const bool vec = p.epi_vec && (SHUF || p.shuffle == 1);
+    const bool res = p.res1 || p.res2;
 #define DSVC_EPI_CASE(A)                                                                                            \
     case A:                                                                                                         \
-        if (!p.epi_vec) epilogue_pass<A, GPP, EPLD>(p, slab, lane, NPL, b, oy_base, ox0, co0, cpass);               \
-        else if (p.epi_f32 && (p.res1 || p.res2)) epilogue_vec<A, true, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
-        else if (p.epi_f32) epilogue_vec<A, false, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
-        else if (p.res1 || p.res2) epilogue_vec<A, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
-        else epilogue_vec<A, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);                 \
+        if (!vec) epilogue_pass<A, GPP, EPLD>(p, R, slab, lane, NPL, b, oy_base, ox0, co0, cpass);                  \
+        else {                                                                                                      \
+            bool done = false;                                                                                      \
+            if constexpr (F32K) {                                                                                   \
+                if (p.epi_f32) {                                                                                    \
+                    if (res) epilogue_vec<A, true, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass); \
+                    else epilogue_vec<A, false, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);   \
+                    done = true;                                                                                    \
+                }                                                                                                   \
+            }                                                                                                       \
+            if (!done) {                                                                                            \
+                if (res) epilogue_vec<A, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);      \
+                else epilogue_vec<A, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);         \
+            }                                                                                                       \
+        }                                                                                                           \
         break;
     switch (p.act) {
         DSVC_EPI_CASE(DSVC_ACT_RELU)
@@ -258,12 +352,7 @@ __device__ __forceinline__ void run_epilogue(const ConvParams& p, const EpiRsrc&
         DSVC_EPI_CASE(DSVC_ACT_SIGMOID)
         DSVC_EPI_CASE(DSVC_ACT_HALF_TANH)
         default:
-            if (!p.epi_vec) epilogue_pass<DSVC_ACT_NONE, GPP, EPLD>(p, slab, lane, NPL, b, oy_base, ox0, co0, cpass);
-            else if (p.epi_f32 && (p.res1 || p.res2)) epilogue_vec<DSVC_ACT_NONE, true, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
-            else if (p.epi_f32) epilogue_vec<DSVC_ACT_NONE, false, GPP, EPLD, NPL, true>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
-            else if (p.res1 || p.res2) epilogue_vec<DSVC_ACT_NONE, true, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
-            else epilogue_vec<DSVC_ACT_NONE, false, GPP, EPLD, NPL>(p, R, slab, lane, b, oy_base, ox0, co0, cpass);
-            break;
+        DSVC_EPI_CASE(DSVC_ACT_NONE)
     }
 #undef DSVC_EPI_CASE
 }

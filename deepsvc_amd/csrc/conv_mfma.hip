@@ -21,6 +21,7 @@
 //   Epilogue (fused): + bias, activation, + residual (optionally gated per channel: SELayer),
 //   + second residual, optional PixelShuffle(2) scatter, cast to the output storage type.
 #include <cstdlib>
+#include <type_traits>
 #include "conv_common.h"
 
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
@@ -558,38 +559,42 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     constexpr int EPC = EPN * 32, EPLD = EPC + 4, GPP = EPC / 4;
     float* slab = (float*)smem + (size_t)wave * (EPM * 32 * EPLD);
     // per-item output placement (dsvc.h: out_bstride): this item's output / residual / bias become image 0 of the epilogue's view
-    ConvParams pe = p;
-    int be = b;
-    if (p.out_bs) {
-        pe.out = (char*)p.out + (size_t)b * p.out_bs;
-        if (p.res1) pe.res1 = (const char*)p.res1 + (size_t)b * p.res1_bs;
-        if (p.bias) pe.bias = p.bias + (size_t)b * p.bias_bs;
-        pe.bias_bs = 0;
-        be = 0;
-    }
-    const EpiRsrc R = make_epi_rsrc(pe);
+    const int be = p.out_bs ? 0 : b;
+    const EpiRsrc R = make_epi_rsrc(p, b);
+    // The passes (<= 2 channel pairs x <= 2 row pairs) are a ROLLED loop around ONE copy of the fused epilogue; only the accumulator ->
+    // slab staging of each pass is expanded with compile-time indices.  (Unrolling the passes around the inlined epilogue dispatch once
+    // exceeded LLVM's pragma-unroll size limit: the loops stayed rolled, `acc` was indexed dynamically and went to scratch memory --
+    // (MT * NT + 1) * 64 bytes per lane, 3x slower NT >= 3 slab variants; caught by tools/bench_subpel.py + kernel-resource-usage.)
+    constexpr int NPN = (NT + EPN - 1) / EPN, NPM = MT / EPM;
+    static_assert(MT % EPM == 0 && NPN <= 2 && NPM <= 2, "slab epilogue: at most 2 x 2 passes of whole row pairs");
+    auto stage = [&](auto n0c, auto m0c) {
+        constexpr int n0 = decltype(n0c)::value, m0 = decltype(m0c)::value;
 #pragma unroll
-    for (int n0 = 0; n0 < NT; n0 += EPN) {
-#pragma unroll
-        for (int m0 = 0; m0 < MT; m0 += EPM) {
-            lds_barrier();
-#pragma unroll
-            for (int e = 0; e < EPN; ++e) {
+        for (int e = 0; e < EPN; ++e) {
+            if constexpr (true) {
                 if (n0 + e < NT) {
 #pragma unroll
-                    for (int m = 0; m < EPM; ++m)
-                        if (m0 + m < MT) {
+                    for (int m = 0; m < EPM; ++m) {
 #pragma unroll
-                            for (int i = 0; i < 16; ++i)
-                                slab[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[m0 + m < MT ? m0 + m : 0][n0 + e < NT ? n0 + e : 0][i];
-                        }
+                        for (int i = 0; i < 16; ++i)
+                            slab[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * EPLD + e * 32 + r] = acc[m0 + m][n0 + e < NT ? n0 + e : 0][i];
+                    }
                 }
             }
-            lds_barrier();
-            const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
-            if (m0 + EPM <= MT) run_epilogue<GPP, EPLD, EPM * 32>(pe, R, slab, lane, be, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);
-            else run_epilogue<GPP, EPLD, 32>(pe, R, slab, lane, be, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);     // odd last row
         }
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int ps = 0; ps < NPN * NPM; ++ps) {
+        const int n0 = (ps / NPM) * EPN, m0 = (ps % NPM) * EPM;      // scalars
+        lds_barrier();
+        if (ps == 0) stage(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+        if constexpr (NPN * NPM > 1) { if (ps == 1) stage(integral_constant<int, (1 / NPM) * EPN>{}, integral_constant<int, (1 % NPM) * EPM>{}); }
+        if constexpr (NPN * NPM > 2) { if (ps == 2) stage(integral_constant<int, (2 / NPM) * EPN>{}, integral_constant<int, (2 % NPM) * EPM>{}); }
+        if constexpr (NPN * NPM > 3) { if (ps == 3) stage(integral_constant<int, (3 / NPM) * EPN>{}, integral_constant<int, (3 % NPM) * EPM>{}); }
+        lds_barrier();
+        const int cpass = (NT - n0 < EPN ? NT - n0 : EPN) * 32;  // channels staged this pass
+        run_epilogue<GPP, EPLD, EPM * 32, sizeof(CT) == 4, true>(p, R, slab, lane, be, oy0 + wave * MT + m0, ox0, ng * NTN + n0 * 32, cpass);
     }
     PROBE_FINISH
 }
@@ -793,6 +798,10 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         DSVC_REQUIRE(oe < 0x7FFFFFF0ll && r1e < 0x7FFFFFF0ll && r2e < 0x7FFFFFF0ll, "conv2d: output/residual tensor above 2 GiB");
         p.out_bytes = (unsigned)oe; p.res1_bytes = (unsigned)r1e; p.res2_bytes = (unsigned)r2e;
         p.epi_vec = d->shuffle == 1 && (d->Cout % 4) == 0 && p.out_vec && (!d->res1 || p.res1_vec) && (!d->res2 || p.res2_vec);
+        // PixelShuffle(2): vector stores of 4 consecutive OUTPUT channels (conv_common.h: epilogue_vec_shuffle)
+        if (d->shuffle == 2 && (d->Cout % 16) == 0 && p.out_vec && (!d->res1 || p.res1_vec) && !item_out && g_dsvc_opt.shuffle_vec &&
+            (d->act == DSVC_ACT_NONE || d->act == DSVC_ACT_RELU || d->act == DSVC_ACT_LRELU))
+            p.epi_vec = 1;
         p.epi_f32 = g_dsvc_opt.epi_f32 && d->out_dtype == DSVC_F32 && (!d->res1 || d->res1_dtype == DSVC_F32) && (!d->res2 || d->res2_dtype == DSVC_F32);
     }
     bool fast = true;

@@ -55,9 +55,10 @@ int dsvc_device_count(void);
  * stride-1 convs with 64 output channels per group from this many tiles on; a huge value turns them off), "reg_epilogue" (1: the
  * generic kernel's LDS-free epilogue where it applies), "patch_prefetch" (1: ... with the next chunk's input patch prefetched),
  * "pp16" (the two-group 3x3 kernel's MFMA shape: 0 = 32x32x16, 2 = 16x16x32, 1 = per variant whichever measured faster),
- * "epi_f32" (1: the vector epilogue issues only fp32 loads / stores when output and residuals are fp32).  Defaults come from
+ * "epi_f32" (1: the vector epilogue issues only fp32 loads / stores when output and residuals are fp32), "shuffle_vec" (1: PixelShuffle(2)
+ * outputs are stored as 4-channel vectors of one output pixel; 0: element by element).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
- * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32).
+ * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);

@@ -120,6 +120,47 @@ def test_conv_slices_shuffle_and_f16_storage():
     report_close("f16 storage in fp32 compute mode (one f16 rounding of the output)", got.nchw().cpu(), want, 6e-4, 2e-4)
 
 
+@pytest.mark.parametrize("compute", ["fp32", "f16"])
+@pytest.mark.parametrize("cin,cq,k,H,W,act,with_res", [(64, 64, 3, 13, 37, 0, False), (96, 96, 3, 9, 33, 2, True), (64, 32, 1, 17, 41, 0, False),
+                                                       (128, 64, 1, 8, 32, 1, True), (32, 4, 3, 5, 9, 0, True), (64, 64, 3, 70, 130, 0, False)])
+def test_subpel_conv_vector_stores(cin, cq, k, H, W, act, with_res, compute):
+    """PixelShuffle(2) folded into the conv store with conv channels in multiples of 16 (image_model.py:25-27 subpel_conv3x3, modules.py:250-254
+    subpel_conv1x1): four consecutive OUTPUT channels of one output pixel per lane (conv_common.h: epilogue_vec_shuffle) -- against
+    torch's conv2d + pixel_shuffle, and bit for bit against the element-wise store path ("shuffle_vec" = 0)."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import _SubpelConv
+    torch.manual_seed(cin + cq + k)
+    ops.set_precision(compute)
+    try:
+        sp = _SubpelConv(cin, cq, 2, k).to(DEV)
+        x, res = torch.randn(2, cin, H, W), torch.randn(2, cq, 2 * H, 2 * W)
+        adt = torch.float16 if compute == "f16" else torch.float32
+        kw = dict(act=act, slope=0.1)
+        if with_res:
+            kw["res1"] = _act(res, adt)
+        got = sp.run(_act(x, adt), out_dtype=adt, **kw)
+        prev = ops.set_option("shuffle_vec", 0)
+        try:
+            elem = sp.run(_act(x, adt), out_dtype=adt, **kw)
+        finally:
+            ops.set_option("shuffle_vec", prev)
+        assert prev == 1
+        assert torch.equal(got.buf, elem.buf), "vector and element-wise subpel stores differ"
+        got = got.nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    w = sp[0].weight.detach().cpu()
+    if compute == "f16":
+        x, w, res = x.to(torch.float16).float(), w.to(torch.float16).float(), res.to(torch.float16).float()
+    want = _torch_act(F.pixel_shuffle(F.conv2d(x, w, sp[0].bias.detach().cpu(), padding=k // 2), 2), act, 0.1)
+    if with_res:
+        want = want + res
+    if compute == "f16":
+        close_f16(f"subpel {cin}->{cq}x4 k{k} f16", got, want)
+    else:
+        report_close(f"subpel {cin}->{cq}x4 k{k} fp32", got, want, 2e-4, 2e-4 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 250, 1100), (64, 32, 256, 1024), (64, 3, 264, 1000), (32, 64, 250, 1090), (32, 3, 256, 1056), (3, 64, 250, 1100)])
 def test_conv3x3_weight_stationary_kernel(cin, cout, H, W):
     """Large-image f16 3x3 convs take the persistent weight-stationary kernel (csrc/conv3x3_ws.hip):
