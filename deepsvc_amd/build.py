@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libdsvc.so")
-SOURCES = ["conv_mfma.hip", "conv3x3_ws.hip", "conv3x3_pp.hip", "conv1x1.hip", "pointwise.hip", "msssim.hip", "entropy.hip", "rans_host.cpp", "host_misc.cpp"]
+SOURCES = ["conv_mfma.hip", "conv3x3_ws.hip", "conv3x3_pp.hip", "conv_head.hip", "conv1x1.hip", "pointwise.hip", "msssim.hip", "entropy.hip", "rans_host.cpp", "host_misc.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "dsvc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("DSVC_BUILD_DEFINES", "").split()
 
@@ -97,7 +97,9 @@ def build(force=False, verbose=False, variant=None, defines=()):
     # No kernel of this library may touch scratch memory: a kernel that does has lost an array or its accumulators to the stack (once: the
     # generic conv's slab-epilogue variants, 3x slower, unnoticed by every parity test).  DSVC_ALLOW_SCRATCH=1 turns the check off.
     spilled = {k: v["scratch"] for k, v in resource_usage(variant).items() if v["scratch"] > SCRATCH_ALLOWED.get(k, 0)}
-    if spilled and not os.environ.get("DSVC_ALLOW_SCRATCH"):
+    if spilled and variant is not None:          # diagnostic builds (probe registers) may spill a little: report only
+        print("note: kernels using scratch memory in this diagnostic build: " + ", ".join(f"{k[28:70]}: {v}" for k, v in sorted(spilled.items())), flush=True)
+    elif spilled and not os.environ.get("DSVC_ALLOW_SCRATCH"):
         raise RuntimeError("kernels using scratch memory (bytes per lane): " + ", ".join(f"{k}: {v}" for k, v in sorted(spilled.items())))
     if relink or _stale(LIB, objs):      # (objects newer than the library: an earlier run compiled them and then stopped)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -108,10 +108,15 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
         for (int k = 0; k < 4; ++k) asm("v_pk_max_i16 %0, %1, 0" : "=v"(u[k]) : "v"(u[k]));
         return make_uint4(u[0], u[1], u[2], u[3]);
     }
+    // LeakyReLU on packed f16 in three VALU ops per pair instead of seven (2 cvt + 2 mul + 2 max + cvt_pk): the mixed-precision FMA
+    // takes the f16 half, multiplies by the fp32 slope and rounds the exact product to f16 once -- the same value as cvt -> mul -> cvt --
+    // and max commutes with that monotonic rounding, so max(x, f16(x * slope)) == f16(max(x, x * slope)) bit for bit.
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float lo = h16_lo(u[k]), hi = h16_hi(u[k]);
-        u[k] = pk_h16(lrelu_f(lo, slope), lrelu_f(hi, slope));
+        unsigned t = 0;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "+v"(t) : "v"(u[k]), "v"(slope));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(u[k]), "v"(slope));
+        asm("v_pk_max_f16 %0, %1, %2" : "=v"(u[k]) : "v"(u[k]), "v"(t));
     }
     return make_uint4(u[0], u[1], u[2], u[3]);
 }

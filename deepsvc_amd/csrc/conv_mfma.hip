@@ -27,6 +27,7 @@
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv_head_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 #ifdef DSVC_PHASE_PROBE
 // Build with DSVC_BUILD_DEFINES=-DDSVC_PHASE_PROBE (deepsvc_amd/build.py) to get per-phase shader-clock totals of wave 0 of
@@ -821,6 +822,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         DSVC_REQUIRE(rc != 1, "conv2d: post_weight (fused 1x1) is not supported for this shape / type combination");
         if (rc == DSVC_OK) { dsvc_count(DSVC_CNT_PP); dsvc_count(DSVC_CNT_PP_POST); }
         return rc;
+    }
+    if (opt.specialised && opt.head) {      // narrow f16 output heads (Cout <= 4) of large images: dot products on the vector ALU
+        const int rc = dsvc_conv_head_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_HEAD);
+        if (rc != 1) return rc;
     }
     if (opt.specialised && opt.conv1x1) {   // f16 pointwise convs: streaming kernel, no LDS staging
         const int rc = dsvc_conv1x1_try((hipStream_t)stream, p, d);

@@ -393,18 +393,30 @@ __global__ void se_partial_kernel(const void* x, int ld, int dt, int64_t HW, int
     }
 }
 
-__global__ void se_gate_kernel(const float* partial, int64_t HW, int C, int hidden, const float* w1, const float* w2, float* gate) {
+__global__ void __launch_bounds__(1024) se_gate_kernel(const float* partial, int64_t HW, int C, int hidden, const float* w1, const float* w2, float* gate) {
     extern __shared__ float sm[];  // mean[C] + hid[hidden]
     float* mean = sm;
     float* hid = sm + C;
     const int b = blockIdx.x;
-    {   // 256 / C threads per channel, each a fixed strided subset of the partials, combined in a fixed order (deterministic);
-        // one thread per channel walked all 512 partials serially: 38 us of pure load latency per gate
-        __shared__ double part[256];
+    {   // blockDim / C threads per channel (1024 threads: 16 for C = 64), each a fixed strided subset of the partials whose loads are all
+        // issued before the first add, combined in a fixed order (deterministic).  History: one thread per channel walking all 512
+        // partials took 38 us of serial load latency per gate; 4 threads per channel with a rolled loop still took 38 us (rocprofv3).
+        __shared__ double part[1024];
         const int lanes = blockDim.x / C, c = threadIdx.x % C, l = threadIdx.x / C;     // C divides 256 (checked on the host)
+        constexpr int U = 8;
         double s = 0.0;
-        if (l < lanes)
-            for (int j = l; j < kSeBlocks; j += lanes) s += (double)partial[((int64_t)b * kSeBlocks + j) * C + c];
+        if (l < lanes) {
+            for (int j0 = l; j0 < kSeBlocks; j0 += lanes * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * lanes;
+                    v[u] = j < kSeBlocks ? partial[((int64_t)b * kSeBlocks + j) * C + c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) s += (double)v[u];
+            }
+        }
         part[threadIdx.x] = s;
         __syncthreads();
         if (threadIdx.x < C) {
@@ -643,7 +655,7 @@ extern "C" int dsvc_se_gate(void* stream, const void* x, int32_t ld, int32_t dty
     else
         hipLaunchKernelGGL(se_partial_kernel, dim3(kSeBlocks, B), dim3(256), 256 * sizeof(float), st, x, ld, dtype, HW, C, partial);
     DSVC_CHECK_LAUNCH("se_partial_kernel");
-    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (C + hidden) * sizeof(float), st, partial, HW, C, hidden, w1, w2, gate);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(1024), (C + hidden) * sizeof(float), st, partial, HW, C, hidden, w1, w2, gate);
     DSVC_CHECK_LAUNCH("se_gate_kernel");
     return DSVC_OK;
 }

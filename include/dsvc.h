@@ -56,14 +56,16 @@ int dsvc_device_count(void);
  * generic kernel's LDS-free epilogue where it applies), "patch_prefetch" (1: ... with the next chunk's input patch prefetched),
  * "pp16" (the two-group 3x3 kernel's MFMA shape: 0 = 32x32x16, 2 = 16x16x32, 1 = per variant whichever measured faster),
  * "epi_f32" (1: the vector epilogue issues only fp32 loads / stores when output and residuals are fp32), "shuffle_vec" (1: PixelShuffle(2)
- * outputs are stored as 4-channel vectors of one output pixel; 0: element by element).  Defaults come from
+ * outputs are stored as 4-channel vectors of one output pixel; 0: element by element), "head" (narrow f16 output heads -- Cout <= 4,
+ * 3x3 over 32 / 64 / 64+64 channels or 7x7 over 16 -- of large images as packed dot products on the vector ALU: 1 = the shapes where that
+ * measured faster than the MFMA kernels, 2 = every covered shape, 0 = none).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
- * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC).
+ * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);
 /* Diagnostic: how many dsvc_conv2d launches each kernel family has taken since the library was loaded (process-wide).
- * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1".  Tests use it to prove that the
+ * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head".  Tests use it to prove that the
  * large-image kernels ran inside a frame that is checked against the reference.  Returns DSVC_E_ARG for an unknown key. */
 int64_t dsvc_get_counter(const char* key);
 /* Diagnostic: time every dsvc_conv2d launch of ONE shape (single-segment k x k conv, `stride`, C -> Cout channels on an H x W input) with

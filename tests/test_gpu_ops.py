@@ -120,6 +120,48 @@ def test_conv_slices_shuffle_and_f16_storage():
     report_close("f16 storage in fp32 compute mode (one f16 rounding of the output)", got.nchw().cpu(), want, 6e-4, 2e-4)
 
 
+@pytest.mark.parametrize("segs,cout,k,H,W,B,act,res_dtype,out_dtype", [
+    ((64,), 3, 3, 250, 1100, 1, 0, None, torch.float32), ((64,), 3, 3, 264, 1000, 1, 4, None, torch.float16), ((32,), 3, 3, 256, 1056, 1, 0, None, torch.float32),
+    ((64,), 2, 3, 250, 1090, 1, 0, torch.float32, torch.float32), ((64, 64), 3, 3, 249, 1033, 1, 1, torch.float16, torch.float16),
+    ((16,), 2, 7, 250, 1100, 1, 0, torch.float32, torch.float32), ((64,), 4, 3, 136, 250, 2, 2, None, torch.float16), ((16,), 2, 7, 130, 260, 2, 0, None, torch.float32)])
+def test_narrow_head_dot_product_kernel(segs, cout, k, H, W, B, act, res_dtype, out_dtype):
+    """Cout <= 4 heads of large f16 images run as v_dot2 on the vector ALU with scalar-loaded weights (csrc/conv_head.hip): ragged tiles,
+    zero padding, two input segments, every activation, residual and output of either type -- against torch on the f16-rounded operands,
+    and against the MFMA kernels ("head" = 0) within the f16 summation-order tolerance."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + k)
+    ops.set_precision("f16")
+    try:
+        m = Conv2d(sum(segs), cout, k, 1, padding=k // 2).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        res = torch.randn(B, cout, H, W) if res_dtype is not None else None
+        kw = dict(act=act, slope=0.1, out_dtype=out_dtype)
+        if res is not None:
+            kw["res1"] = _act(res, res_dtype)
+        ins = [_act(x, torch.float16) for x in xs]
+        n0 = ops.get_counter("conv_head")
+        prev = ops.set_option("head", 2)          # 2: also the shapes the dispatcher leaves to the MFMA kernels by default (64 -> 3, 64+64 -> 3)
+        got = m.run(ins, **kw)
+        assert ops.get_counter("conv_head") == n0 + 1, "the narrow-head kernel did not take this launch"
+        assert ops.set_option("head", 0) == 2
+        try:
+            other = m.run(ins, **kw)
+        finally:
+            ops.set_option("head", prev)
+        assert ops.get_counter("conv_head") == n0 + 1
+        got, other = got.nchw().float().cpu(), other.nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    x = torch.cat(xs, 1).to(torch.float16).float()
+    w = m.weight.detach().cpu().to(torch.float16).float()
+    want = _torch_act(F.conv2d(x, w, m.bias.detach().cpu(), padding=k // 2), act, 0.1)
+    if res is not None:
+        want = want + (res.to(torch.float16).float() if res_dtype == torch.float16 else res)
+    close_f16(f"head {segs}->{cout} k{k}", got, want, out_f16=out_dtype == torch.float16)
+    close_f16(f"head {segs}->{cout} k{k} vs MFMA kernels", got, other, out_f16=out_dtype == torch.float16, both_f16=out_dtype == torch.float16)
+
+
 @pytest.mark.parametrize("compute", ["fp32", "f16"])
 @pytest.mark.parametrize("cin,cq,k,H,W,act,with_res", [(64, 64, 3, 13, 37, 0, False), (96, 96, 3, 9, 33, 2, True), (64, 32, 1, 17, 41, 0, False),
                                                        (128, 64, 1, 8, 32, 1, True), (32, 4, 3, 5, 9, 0, True), (64, 64, 3, 70, 130, 0, False)])
