@@ -27,7 +27,10 @@ namespace {
 // register-epilogue variant (see the header): act(x) = max(x, x * act_slope) (slope 1: none, 0: ReLU)
 // Up to two input segments of whole 32-channel chunks (the virtual torch.cat of the up-path ConvBlockResidual shortcuts);
 // HAS_GATE: out = act(conv) + gate[c] * res1 (the SE gate of modules.py:226-247, batch 1).
-template <int KS, int NT, bool HAS_R1, bool HAS_GATE>
+// COAL: global memory is touched in whole pixel rows -- every load / store instruction moves 1 KB made of complete channel rows (8 lanes per
+// 128-byte row) instead of 32-byte pieces of 32 different rows -- and a wave-private LDS tile (pitch = row + 16 bytes: conflict-free both
+// ways) transposes between that layout and the MFMA operand layout.  Same arithmetic, same rounding: only the route of the bytes changes.
+template <int KS, int NT, bool HAS_R1, bool HAS_GATE, bool COAL = false>
 __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p, int nunits, float act_slope) {
     DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,11 +83,63 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
     };
     const int b_lane = r * ROWB + h * 16;
     uint4 a_cur[KS], a_nxt[KS], r_cur[NT * 2], r_nxt[NT * 2];
-    load_a(unit, a_cur);
-    if constexpr (HAS_R1) load_r(unit, r_cur);
+    // ---- COAL: row-granular global access + LDS transposition ----
+    constexpr int PPI = KS * 2, PPO = NT * 4;                       // 16-byte pieces per input / output pixel row
+    constexpr int TP = ((PPI > PPO ? PPI : PPO) + 1) * 16;          // tile pitch in bytes
+    char* tile = smem + (size_t)NCH * p.Np * ROWB + (size_t)2 * p.Np * sizeof(float) + (size_t)wave * (32 * TP);
+    auto load_g = [&](int u, uint4 (&g)[KS]) {                      // input rows of unit u, vector v = 64 i + lane -> (pixel v / PPI, piece v % PPI)
+        const bool uok = u < nunits;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const int v = i * 64 + lane, px = v / PPI, pc = v - px * PPI;
+            const unsigned pix = (unsigned)u * 32 + px;
+            const unsigned m = (uok && pix < npix) ? 0u : OOB;
+            g[i] = (pc < ks0 * 2) ? buf_load16(rin, (pix * pitch + (unsigned)pc * 16u) | m)
+                                  : buf_load16(rin1, (pix * pitch1 + (unsigned)(pc - ks0 * 2) * 16u) | m);
+        }
+    };
+    auto load_gr = [&](int u, uint4 (&g)[NT * 2]) {                 // residual rows in the same layout as the output rows
+        const bool uok = u < nunits;
+#pragma unroll
+        for (int i = 0; i < NT * 2; ++i) {
+            const int v = i * 64 + lane, px = v / PPO, pc = v - px * PPO;
+            const unsigned pix = (unsigned)u * 32 + px;
+            g[i] = buf_load16(rr1, (pix * rpitch + (unsigned)pc * 16u) | ((uok && pix < npix && pc * 8 < p.Cout) ? 0u : OOB));
+        }
+    };
+    auto tile_sync = [&]() { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };   // DS ops of a wave execute in order: only the compiler must not reorder
+    if constexpr (COAL) {
+        load_g(unit, a_nxt);
+        if constexpr (HAS_R1) load_gr(unit, r_nxt);
+    } else {
+        load_a(unit, a_cur);
+        if constexpr (HAS_R1) load_r(unit, r_cur);
+    }
     for (; unit < nunits; unit += nwaves) {
-        load_a(unit + nwaves, a_nxt);                          // prefetch (masked past the end)
-        if constexpr (HAS_R1) load_r(unit + nwaves, r_nxt);
+        if constexpr (COAL) {
+            // rows -> tile -> operand layout: lane (r, h) takes piece 2 ks + h of pixel r
+#pragma unroll
+            for (int i = 0; i < KS; ++i) { const int v = i * 64 + lane, px = v / PPI, pc = v - px * PPI; *(uint4*)(tile + px * TP + pc * 16) = a_nxt[i]; }
+            tile_sync();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a_cur[ks] = *(const uint4*)(tile + r * TP + (2 * ks + h) * 16);
+            tile_sync();
+            if constexpr (HAS_R1) {
+#pragma unroll
+                for (int i = 0; i < NT * 2; ++i) { const int v = i * 64 + lane, px = v / PPO, pc = v - px * PPO; *(uint4*)(tile + px * TP + pc * 16) = r_nxt[i]; }
+                tile_sync();
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int P = 0; P < 2; ++P) r_cur[n * 2 + P] = *(const uint4*)(tile + r * TP + (n * 4 + 2 * P + h) * 16);
+                tile_sync();
+            }
+            load_g(unit + nwaves, a_nxt);                          // prefetch (masked past the end)
+            if constexpr (HAS_R1) load_gr(unit + nwaves, r_nxt);
+        } else {
+            load_a(unit + nwaves, a_nxt);                          // prefetch (masked past the end)
+            if constexpr (HAS_R1) load_r(unit + nwaves, r_nxt);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned pix = (unsigned)unit * 32 + r;
         const bool okp = pix < npix;
@@ -129,16 +184,30 @@ __global__ void __launch_bounds__(256) conv1x1_direct_kernel(const ConvParams p,
             const int co = N0 * 32 + 16 * P + 8 * h;                                                                 \
             v4u_t ov;                                                                                                \
             ov.x = pk_h16(v[0], v[1]); ov.y = pk_h16(v[2], v[3]); ov.z = pk_h16(v[4], v[5]); ov.w = pk_h16(v[6], v[7]); \
-            __builtin_amdgcn_raw_buffer_store_b128(ov, rout, (pix * opitch + (unsigned)co * 2) | ((okp && co < p.Cout) ? 0u : OOB), 0, 0); \
+            if constexpr (COAL) *(v4u_t*)(tile + r * TP + (N0 * 4 + 2 * P + h) * 16) = ov;                           \
+            else __builtin_amdgcn_raw_buffer_store_b128(ov, rout, (pix * opitch + (unsigned)co * 2) | ((okp && co < p.Cout) ? 0u : OOB), 0, 0); \
         }                                                                                                            \
     }
         C1D_TILE(0) C1D_TILE(1) C1D_TILE(2) C1D_TILE(3)
 #undef C1D_TILE
+        if constexpr (COAL) {                                      // tile -> whole output rows
+            tile_sync();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
-        if constexpr (HAS_R1) {
+            for (int i = 0; i < NT * 2; ++i) {
+                const int v = i * 64 + lane, px = v / PPO, pc = v - px * PPO;
+                const uint4 o = *(const uint4*)(tile + px * TP + pc * 16);
+                const unsigned opx = (unsigned)unit * 32 + px;
+                v4u_t ov; ov.x = o.x; ov.y = o.y; ov.z = o.z; ov.w = o.w;
+                __builtin_amdgcn_raw_buffer_store_b128(ov, rout, (opx * opitch + (unsigned)pc * 16u) | ((opx < npix && pc * 8 < p.Cout) ? 0u : OOB), 0, 0);
+            }
+            tile_sync();
+        } else {
 #pragma unroll
-            for (int i = 0; i < NT * 2; ++i) r_cur[i] = r_nxt[i];
+            for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+            if constexpr (HAS_R1) {
+#pragma unroll
+                for (int i = 0; i < NT * 2; ++i) r_cur[i] = r_nxt[i];
+            }
         }
     }
 }
@@ -221,12 +290,20 @@ int launch_1x1(hipStream_t st, const ConvParams& p, int nunits) {
 
 template <int KS, int NT>
 int launch_1x1_direct(hipStream_t st, const ConvParams& p, int nunits, float act_slope) {
-    const size_t lds = (size_t)((KS + 1) / 2) * p.Np * ROWB + (size_t)2 * p.Np * sizeof(float);
+    const bool coal = g_dsvc_opt.conv1x1_rows != 0;
+    constexpr int TP = ((KS * 2 > NT * 4 ? KS * 2 : NT * 4) + 1) * 16;
+    const size_t lds = (size_t)((KS + 1) / 2) * p.Np * ROWB + (size_t)2 * p.Np * sizeof(float) + (coal ? (size_t)4 * 32 * TP : 0);
     int grid = (nunits + 3) / 4;
     if (grid > 256 * 4) grid = 256 * 4;
-    if (p.res1 && p.res1_scale) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, true, true>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
-    else if (p.res1) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, true, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
-    else hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, false, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);
+#define C1D_LAUNCH(R1, GATE)                                                                                                          \
+    do {                                                                                                                              \
+        if (coal) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, R1, GATE, true>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope); \
+        else hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, R1, GATE, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);     \
+    } while (0)
+    if (p.res1 && p.res1_scale) C1D_LAUNCH(true, true);
+    else if (p.res1) C1D_LAUNCH(true, false);
+    else C1D_LAUNCH(false, false);
+#undef C1D_LAUNCH
     DSVC_CHECK_LAUNCH("conv1x1_direct_kernel");
     return DSVC_OK;
 }
