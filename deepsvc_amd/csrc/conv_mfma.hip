@@ -635,6 +635,10 @@ int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, in
             return launch_cfg<CT, 2, 4, true, true>(st, p, ngroups, lds);
         }
         if (MT == 4) return launch_cfg<CT, 4, 2, true>(st, p, ngroups, lds);      // 16x32-pixel tiles: f16, vector staging, 64 output channels per group
+        if (fast && MT == 1 && NT <= 3 && p.patchpf)         // small images (entropy scan, 1/8 - 1/16 resolution): 4x32 tiles + patch prefetch
+            return NT == 1 ? launch_cfg<CT, 1, 1, true, false, 4>(st, p, ngroups, lds)
+                 : NT == 2 ? launch_cfg<CT, 1, 2, true, false, 4>(st, p, ngroups, lds) : launch_cfg<CT, 1, 3, true, false, 4>(st, p, ngroups, lds);
+        if (fast && MT == 2 && NT == 1 && p.patchpf) return launch_cfg<CT, 2, 1, true, false, 6>(st, p, ngroups, lds);
     }
     if constexpr (sizeof(CT) == 4) {
         if (fast && MT == 2 && NT == 2 && p.patchpf) return launch_cfg<CT, 2, 2, true, false, 6>(st, p, ngroups, lds);     // fp32: slab epilogue + patch prefetch
@@ -899,6 +903,12 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         //  121 us for the tap-level pipeline without patch prefetch -- not taken)
         const bool f32_pf = d->compute == DSVC_F32 && fast && d->kh == 3 && d->kw == 3 && d->stride == 1 && !p.s2d;
         p.patchpf = (p.regepi || f32_pf) && opt.patch_prefetch && MT == 2 && NT == 2 && same_type && PH * PW <= 6 * 64;
+        // small f16 launches (a few dozen to a few hundred workgroups, each a serial chain of stage -> MFMA per 32-channel chunk: the
+        // entropy scan and the 1/8 - 1/16 resolution layers, ~250 launches per 1080p frame): the next chunk's patch loads ride under
+        // the current chunk's weight commit and MFMAs (tools/phase_probe_tiny.py: patch staging was 25-30 % of a workgroup's clocks)
+        if (opt.patch_prefetch >= 1 && opt.small_pf && d->compute == DSVC_F16 && fast && same_type && p.nchunks >= 2 && !p.regepi &&
+            ((MT == 1 && NT <= 3 && PH * PW <= 4 * 64) || (MT == 2 && NT == 1 && PH * PW <= 6 * 64)))
+            p.patchpf = 1;
     }
     const size_t lds_epi = p.regepi ? 0 : (size_t)4 * (MT >= 2 ? 2 : 1) * 32 * ((NT >= 2 ? 64 : 32) + 4) * sizeof(float);
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;

@@ -59,9 +59,10 @@ int dsvc_device_count(void);
  * outputs are stored as 4-channel vectors of one output pixel; 0: element by element), "head" (narrow f16 output heads -- Cout <= 4,
  * 3x3 over 32 / 64 / 64+64 channels or 7x7 over 16 -- of large images as packed dot products on the vector ALU: 1 = the shapes where that
  * measured faster than the MFMA kernels, 2 = every covered shape, 0 = none), "conv1x1_rows" (1: the pointwise kernel reads and writes
- * whole pixel rows and transposes to the MFMA operand layout through LDS; 0: lanes address 32-byte pieces of 32 rows).  Defaults come from
+ * whole pixel rows and transposes to the MFMA operand layout through LDS; 0: lanes address 32-byte pieces of 32 rows), "small_pf" (1: the
+ * generic kernel's 4x32 / 8x32 x 32-channel variants prefetch the next channel chunk's input patch: small images, f16 storage).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
- * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS).
+ * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);
