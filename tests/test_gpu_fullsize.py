@@ -147,12 +147,13 @@ def test_wide_256x1024_fp32_bytes_and_tensors_equal_reference(gwide):
 
 def test_wide_256x1024_f16_fast_kernels_against_reference(gwide):
     from deepsvc_amd import ops
-    keys = ("conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1")
+    keys = ("conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head")
     before = {k: ops.get_counter(k) for k in keys}
     _f16_chain_against_reference(gwide, "s256x1024", 256, 1024, 3, features_of=(3,))
     took = {k: ops.get_counter(k) - before[k] for k in keys}
     print(f"[parity] launches taken by the large-image kernels inside these frames: {took}")
     assert took["conv3x3_pp"] >= 3 * 60 and took["conv3x3_pp_fused_tail"] >= 3 * 6 and took["conv1x1"] >= 3 * 20, took
+    assert took["conv_head"] >= 3 * 2, took          # the dot-product heads (SpyNet's 16 -> 2, the 32 -> 3 / 64 -> 2 outputs) ran inside these frames
 
 
 # ------------------------------------------------------------------------------------------------------------
