@@ -297,8 +297,16 @@ int launch_1x1_direct(hipStream_t st, const ConvParams& p, int nunits, float act
     if (grid > 256 * 4) grid = 256 * 4;
 #define C1D_LAUNCH(R1, GATE)                                                                                                          \
     do {                                                                                                                              \
-        if (coal) hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, R1, GATE, true>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope); \
-        else hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, R1, GATE, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);     \
+        if (coal) {                                                                                                                   \
+            auto kern = conv1x1_direct_kernel<KS, NT, R1, GATE, true>;                                                                \
+            static bool attr_set = false;                    /* 128 -> 128: 42 KB of weights + 35 KB of transposition tiles */        \
+            if (!attr_set && lds > 64 * 1024) {                                                                                       \
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+                if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }       \
+                attr_set = true;                                                                                                      \
+            }                                                                                                                         \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, nunits, act_slope);                                           \
+        } else hipLaunchKernelGGL((conv1x1_direct_kernel<KS, NT, R1, GATE, false>), dim3(grid), dim3(256), lds, st, p, nunits, act_slope);   \
     } while (0)
     if (p.res1 && p.res1_scale) C1D_LAUNCH(true, true);
     else if (p.res1) C1D_LAUNCH(true, false);

@@ -6,6 +6,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int64_t kIdx32 = (1ll << 32) - (1ll << 24);   // item counts below this take the 32-bit index decomposition (the grid-stride step stays below 2^24)
 inline unsigned grid_for(int64_t n) {
     int64_t g = (n + kThreads - 1) / kThreads;
     const int64_t cap = 256 * 16;  // 16 workgroups per CU, grid-stride beyond
@@ -16,18 +17,22 @@ inline unsigned grid_for(int64_t n) {
 // grid_sample(bilinear, padding_mode='border', align_corners=True) with grid = base + flow/((size-1)/2):
 // the sampling position in pixels is (x + fx, y + fy), clipped to [0, size-1]; taps beyond the edge
 // carry zero weight.  One thread per (pixel, 4-channel group) when C % 4 == 0, else per element.
-template <int VEC>
+// IT: index type of the work-item decomposition.  `unsigned` whenever the item count fits (always, up to 4K): the chains of 64-bit
+// div / mod by run-time values (4-6 per item, ~100 instructions each) had made the 64-channel warp VALU-bound at 183 us where its bytes
+// move in ~100 us (rocprofv3, round 3); int64_t remains for larger problems.
+template <int VEC, typename IT>
 __global__ void warp_kernel(const void* in, int in_ld, int in_dt, const float* flow, int flow_ld,
                             void* out, int out_ld, int out_dt, int B, int H, int W, int C) {
     DSVC_F16_SAT();
     const int cg = (C + VEC - 1) / VEC;
-    const int64_t total = (int64_t)B * H * W * cg;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const int64_t pix = i / cg;
-        const int x = (int)(pix % W);
-        const int y = (int)((pix / W) % H);
-        const int64_t b = pix / ((int64_t)W * H);
+    const IT total = (IT)B * H * W * cg;
+    for (IT i = (IT)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * blockDim.x) {
+        const IT pixi = i / (IT)cg, rowi = pixi / (IT)W;
+        const int g = (int)(i - pixi * cg);
+        const int64_t pix = (int64_t)pixi;
+        const int x = (int)(pixi - rowi * W);
+        const int64_t b = (int64_t)(rowi / (IT)H);
+        const int y = (int)(rowi - (IT)b * H);
         const float fx = flow[pix * flow_ld], fy = flow[pix * flow_ld + 1];
         float sx = fminf(fmaxf((float)x + fx, 0.f), (float)(W - 1));
         float sy = fminf(fmaxf((float)y + fy, 0.f), (float)(H - 1));
@@ -91,18 +96,19 @@ __global__ void pool2x2_kernel(int mode, const void* in, int in_ld, void* out, i
 }
 
 // 16 bytes per thread (8 f16 / 4 fp32 channels): the element-wise kernel above moves 2-4 bytes per lane (1.5 TB/s at 1080p)
-template <bool H16>
+template <bool H16, typename IT>
 __global__ void pool2x2_vec_kernel(int mode, const void* in, int in_ld, void* out, int out_ld, int B, int H, int W, int C) {
     DSVC_F16_SAT();
     constexpr int V = H16 ? 8 : 4;
     const int Ho = H / 2, Wo = W / 2, CV = C / V;
-    const int64_t total = (int64_t)B * Ho * Wo * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CV) * V;
-        const int64_t pix = i / CV;
-        const int x = (int)(pix % Wo);
-        const int y = (int)((pix / Wo) % Ho);
-        const int64_t b = pix / ((int64_t)Wo * Ho);
+    const IT total = (IT)B * Ho * Wo * CV;
+    for (IT i = (IT)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * blockDim.x) {
+        const IT pixi = i / (IT)CV, rowi = pixi / (IT)Wo;
+        const int c = (int)(i - pixi * CV) * V;
+        const int64_t pix = (int64_t)pixi;
+        const int x = (int)(pixi - rowi * Wo);
+        const int64_t b = (int64_t)(rowi / (IT)Ho);
+        const int y = (int)(rowi - (IT)b * Ho);
         const int64_t p00 = ((b * H + 2 * y) * W + 2 * x) * (int64_t)in_ld + c;
         const int64_t offs[4] = {p00, p00 + in_ld, p00 + (int64_t)W * in_ld, p00 + (int64_t)(W + 1) * in_ld};
         float v[4][8];
@@ -157,19 +163,19 @@ __global__ void pixel_shuffle_nchw_kernel(const float* in, void* out, int out_ld
 // Same op, one thread per OUTPUT PIXEL and 8 channels: lanes walk the source x (64 consecutive floats of one plane per load,
 // coalesced) and write their pixel's 8 channels as one 16-byte (f16) / two 16-byte (fp32) stores -- the element-wise kernel
 // above wrote 2 bytes per thread at a 32-byte stride (216 us for the 1080p inter-layer feature, ~0.9 TB/s).
-template <bool H16>
+template <bool H16, typename IT>
 __global__ void pixel_shuffle_nchw_vec8_kernel(const float* __restrict__ in, void* out, int out_ld, int B, int Co, int Hin, int Win, int r) {
     DSVC_F16_SAT();
-    const int64_t total = (int64_t)B * Hin * r * r * Win * (Co / 8);
+    const IT total = (IT)B * Hin * r * r * Win * (Co / 8);
     const int64_t plane = (int64_t)Hin * Win;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int xi = (int)(i % Win);
-        int64_t t = i / Win;
-        const int rx = (int)(t % r); t /= r;
-        const int ry = (int)(t % r); t /= r;
-        const int c8 = (int)(t % (Co / 8)) * 8; t /= (Co / 8);
-        const int yi = (int)(t % Hin);
-        const int64_t b = t / Hin;
+    for (IT i = (IT)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * blockDim.x) {
+        IT t = i / (IT)Win, u;
+        const int xi = (int)(i - t * Win);
+        u = t / (IT)r; const int rx = (int)(t - u * r); t = u;
+        u = t / (IT)r; const int ry = (int)(t - u * r); t = u;
+        u = t / (IT)(Co / 8); const int c8 = (int)(t - u * (Co / 8)) * 8; t = u;
+        u = t / (IT)Hin; const int yi = (int)(t - u * Hin);
+        const int64_t b = (int64_t)u;
         const float* src = in + ((b * Co + c8) * r * r + ry * r + rx) * plane + (int64_t)yi * Win + xi;
         float v[8];
 #pragma unroll
@@ -259,17 +265,19 @@ inline bool vec8_ok(const void* p, int ld, int dt, int C) {
 }
 
 // warp, 8 channels per thread, 16-B accesses (the 64-channel feature warp of InterLayerPrediction, modules.py:429)
+template <typename IT>
 __global__ void warp8_kernel(const void* in, int in_ld, int in_dt, const float* flow, int flow_ld,
                              void* out, int out_ld, int out_dt, int B, int H, int W, int C) {
     DSVC_F16_SAT();
     const int cg = C / 8;
-    const int64_t total = (int64_t)B * H * W * cg;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const int64_t pix = i / cg;
-        const int x = (int)(pix % W);
-        const int y = (int)((pix / W) % H);
-        const int64_t b = pix / ((int64_t)W * H);
+    const IT total = (IT)B * H * W * cg;
+    for (IT i = (IT)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * blockDim.x) {
+        const IT pixi = i / (IT)cg, rowi = pixi / (IT)W;
+        const int g = (int)(i - pixi * cg);
+        const int64_t pix = (int64_t)pixi;
+        const int x = (int)(pixi - rowi * W);
+        const int64_t b = (int64_t)(rowi / (IT)H);
+        const int y = (int)(rowi - (IT)b * H);
         const float2 f = *(const float2*)(flow + pix * flow_ld);
         const float sx = fminf(fmaxf((float)x + f.x, 0.f), (float)(W - 1)), sy = fminf(fmaxf((float)y + f.y, 0.f), (float)(H - 1));
         const float x0f = floorf(sx), y0f = floorf(sy);
@@ -534,13 +542,16 @@ extern "C" int dsvc_warp_bilinear_border(void* stream, const void* in, int32_t i
     hipStream_t st = (hipStream_t)stream;
     if (vec8_ok(in, in_ld, in_dtype, C) && vec8_ok(out, out_ld, out_dtype, C) && flow_ld % 2 == 0 && ((uintptr_t)flow % 8) == 0) {
         const int64_t n = (int64_t)B * H * W * (C / 8);
-        hipLaunchKernelGGL(warp8_kernel, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+        if (n < kIdx32) hipLaunchKernelGGL(warp8_kernel<unsigned>, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+        else hipLaunchKernelGGL(warp8_kernel<int64_t>, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
     } else if (C % 4 == 0) {
         const int64_t n = (int64_t)B * H * W * (C / 4);
-        hipLaunchKernelGGL(warp_kernel<4>, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+        if (n < kIdx32) hipLaunchKernelGGL((warp_kernel<4, unsigned>), dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+        else hipLaunchKernelGGL((warp_kernel<4, int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
     } else {
         const int64_t n = (int64_t)B * H * W * C;
-        hipLaunchKernelGGL(warp_kernel<1>, dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+        if (n < kIdx32) hipLaunchKernelGGL((warp_kernel<1, unsigned>), dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
+        else hipLaunchKernelGGL((warp_kernel<1, int64_t>), dim3(grid_for(n)), dim3(kThreads), 0, st, in, in_ld, in_dtype, flow, flow_ld, out, out_ld, out_dtype, B, H, W, C);
     }
     DSVC_CHECK_LAUNCH("warp_kernel");
     return DSVC_OK;
@@ -562,10 +573,14 @@ extern "C" int dsvc_pool2x2(void* stream, int32_t mode, const void* in, int32_t 
     const int64_t n = (int64_t)B * (H / 2) * (W / 2) * C;
     const int V = dtype == DSVC_F16 ? 8 : 4, es = dsvc_esize(dtype);
     if (C % V == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && ((int64_t)in_ld * es) % 16 == 0 && ((int64_t)out_ld * es) % 16 == 0) {
-        if (dtype == DSVC_F16)
-            hipLaunchKernelGGL(pool2x2_vec_kernel<true>, dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
-        else
-            hipLaunchKernelGGL(pool2x2_vec_kernel<false>, dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
+        const bool i32 = n / V < kIdx32;
+        if (dtype == DSVC_F16) {
+            if (i32) hipLaunchKernelGGL((pool2x2_vec_kernel<true, unsigned>), dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
+            else hipLaunchKernelGGL((pool2x2_vec_kernel<true, int64_t>), dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
+        } else {
+            if (i32) hipLaunchKernelGGL((pool2x2_vec_kernel<false, unsigned>), dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
+            else hipLaunchKernelGGL((pool2x2_vec_kernel<false, int64_t>), dim3(grid_for(n / V)), dim3(kThreads), 0, (hipStream_t)stream, mode, in, in_ld, out, out_ld, B, H, W, C);
+        }
         DSVC_CHECK_LAUNCH("pool2x2_vec_kernel");
         return DSVC_OK;
     }
@@ -579,10 +594,13 @@ extern "C" int dsvc_pixel_shuffle_nchw(void* stream, const float* in, void* out,
     DSVC_REQUIRE(in && out && B > 0 && Cout > 0 && Hin > 0 && Win > 0 && r >= 1 && out_ld >= Cout && dt_ok(out_dtype), "pixel_shuffle: bad argument");
     const int64_t n = (int64_t)B * Cout * Hin * r * Win * r;
     if (Cout % 8 == 0 && ((uintptr_t)out & 15) == 0 && ((int64_t)out_ld * dsvc_esize(out_dtype)) % 16 == 0) {
-        if (out_dtype == DSVC_F16)
-            hipLaunchKernelGGL(pixel_shuffle_nchw_vec8_kernel<true>, dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);
-        else
-            hipLaunchKernelGGL(pixel_shuffle_nchw_vec8_kernel<false>, dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);
+        if (out_dtype == DSVC_F16) {
+            if (n / 8 < kIdx32) hipLaunchKernelGGL((pixel_shuffle_nchw_vec8_kernel<true, unsigned>), dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);
+            else hipLaunchKernelGGL((pixel_shuffle_nchw_vec8_kernel<true, int64_t>), dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);
+        } else {
+            if (n / 8 < kIdx32) hipLaunchKernelGGL((pixel_shuffle_nchw_vec8_kernel<false, unsigned>), dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);
+            else hipLaunchKernelGGL((pixel_shuffle_nchw_vec8_kernel<false, int64_t>), dim3(grid_for(n / 8)), dim3(kThreads), 0, (hipStream_t)stream, in, out, out_ld, B, Cout, Hin, Win, r);
+        }
         DSVC_CHECK_LAUNCH("pixel_shuffle_nchw_vec8_kernel");
         return DSVC_OK;
     }

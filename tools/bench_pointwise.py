@@ -1,21 +1,41 @@
-"""Launch time of the layout / pointwise kernels at 1080p sizes.   python tools/bench_pointwise.py"""
-import os, sys, torch
+"""Full-resolution pointwise kernels of a 1080p P-frame, stand-alone (warp of the 64-channel feature, 2x2 pooling, PixelShuffle(4) of the
+inter-layer feature): time and bytes moved.   python tools/bench_pointwise.py"""
+import os, sys
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from deepsvc_amd import ops
+from deepsvc_amd import ops  # noqa: E402
 
 dev = "cuda:0"
-def timeit(name, fn, nbytes, n=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / n * 1e3
-    print(f"{name:44s} {us:8.1f} us  {nbytes/us/1e3:7.0f} GB/s", flush=True)
+H, W = 1088, 1920
 
-sm = torch.randn(1, 256, 272, 480, device=dev)
-out = ops.new_act(1, 1088, 1920, 16, torch.float16, dev)
-timeit("pixel_shuffle4 [256,272,480] f32 -> f16 NHWC", lambda: ops.pixel_shuffle_nchw(sm, 4, out=out), sm.numel() * 4 + out.buf.numel() * 2)
-x = ops.new_act(1, 1088, 1920, 64, torch.float16, dev); x.buf.normal_()
-timeit("pool2x2 avg 64ch f16 @1080p", lambda: ops.pool2x2(x, "avg"), x.buf.numel() * 2 * 1.25)
+
+def timeit(fn, iters=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+torch.manual_seed(0)
+x = ops.to_act(torch.randn(1, 64, H, W, device=dev), torch.float16)
+flow = ops.to_act(torch.randn(1, 2, H, W, device=dev) * 3, torch.float32)
+out = ops.new_act(1, H, W, 64, torch.float16, dev)
+t = timeit(lambda: ops.warp(x, flow, out))
+print(f"warp 64 ch f16 @{H}x{W}: {t:6.1f} us ({(2 * 64 * 2 + 8) * H * W / t / 1e6:4.2f} TB/s of in + out + flow)")
+x3 = ops.to_act(torch.randn(1, 3, H, W, device=dev), torch.float32)
+o3 = ops.new_act(1, H, W, 3, torch.float32, dev)
+t = timeit(lambda: ops.warp(x3, flow, o3))
+print(f"warp 3 ch fp32 @{H}x{W}: {t:6.1f} us")
+po = ops.new_act(1, H // 2, W // 2, 64, torch.float16, dev)
+t = timeit(lambda: ops.pool2x2(x, "avg", po))
+print(f"avg-pool 2x2 64 ch f16 @{H}x{W}: {t:6.1f} us ({1.25 * 64 * 2 * H * W / t / 1e6:4.2f} TB/s)")
+xn = torch.randn(1, 64 * 16, H // 4, W // 4, device=dev)
+so = ops.new_act(1, H, W, 64, torch.float16, dev)
+t = timeit(lambda: ops.pixel_shuffle_nchw(xn, 4, so))
+print(f"PixelShuffle(4) nchw fp32 -> nhwc f16 64 ch @{H}x{W}: {t:6.1f} us ({64 * 6 * H * W / t / 1e6:4.2f} TB/s)")
