@@ -13,7 +13,9 @@ dev = "cuda:0"
 L = ctypes.CDLL(N.LIB_PATH)
 names = ["barrier(pre-stage)", "patch staging", "weight staging", "barrier(pre-mfma)", "mfma phase", "epilogue"]
 SHAPES = [((64,), 32, 3, 68, 120, 1), ((64,), 32, 3, 68, 120, 4), ((96,), 48, 3, 68, 120, 1), ((96, 48), 96, 3, 68, 120, 1), ((64,), 64, 3, 136, 240, 1),
-          ((96,), 96, 3, 136, 240, 1), ((64,), 64, 1, 136, 240, 1), ((128,), 128, 3, 272, 480, 1)]
+          ((96,), 96, 3, 136, 240, 1), ((64,), 64, 1, 136, 240, 1), ((128,), 128, 3, 272, 480, 1),
+          # the large shapes of DESIGN.md section 9 item 1b
+          ((96,), 96, 3, 544, 960, 1), ((64, 64), 64, 3, 1088, 1920, 1), ((64,), 32, 7, 1088, 1920, 1), ((32,), 64, 7, 1088, 1920, 1)]
 for segs, cout, k, H, W, B in SHAPES:
     m = Conv2d(sum(segs), cout, k, 1, padding=k // 2).to(dev)
     ins = [ops.Act(torch.randn((B, H, W, c), device=dev).to(torch.float16)) for c in segs]
