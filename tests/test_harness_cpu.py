@@ -93,7 +93,9 @@ dist.destroy_process_group()
 """
 
 
-def test_two_rank_gather_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_gather_gloo(tmp_path, world):
+    """2 ranks (3 + 2 GOPs: a ragged gather) and the 8 ranks of the driver's scaling run (5 GOPs: three ranks have nothing to code)."""
     import subprocess
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -101,9 +103,9 @@ def test_two_rank_gather_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in range(2)]
-    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
