@@ -25,12 +25,14 @@ and timed the same way, are reported inside the line:
   "cpu_baseline" (+ "cpu_baseline_1thread") the CPU oracle timed on this host (N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
 import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,9 +43,8 @@ HBM_PEAK = 8.0e12                                    # B/s
 FLOP_PER_PX = {2: 8.571e6,      # GOP = 7: mean over the 6 P-frames (first P 8.453e6, steady-state 8.594e6)
                3: 8.076e6}      # GOP = 12 with the intra-coded key frame: mean over all 12 frames
 GOP_OF = {2: 7, 3: 12}
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc.json")
-if not os.path.exists(PMC_FILE):
-    PMC_FILE = os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_dominant_kernel_pmc.json") for r in (4, 3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r04_dominant_kernel_pmc.json"))
 
 
 def parse():
@@ -142,13 +143,26 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         return launch_ranks(args)
-    import torch
-    sys.setswitchinterval(args.switch_interval)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(env_world or "1")
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    # N ranks share one host: each pins itself to ITS share of the cores this job may use (local ranks take consecutive slices) before
+    # any worker thread exists -- lane threads, the range-coder / decode pools and torch's own pool are created later and inherit the
+    # mask -- so that 8 ranks x (lane threads + coder threads) do not migrate over each other's cores.  DSVC_BENCH_NO_PIN=1 turns it off.
+    host = {"cores_visible": None, "cores_pinned": None}
+    if hasattr(os, "sched_getaffinity"):
+        allowed = sorted(os.sched_getaffinity(0))
+        host["cores_visible"] = len(allowed)
+        if world > 1 and not os.environ.get("DSVC_BENCH_NO_PIN") and len(allowed) >= world:
+            lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            lr = local_rank % lw
+            share = allowed[lr * len(allowed) // lw:(lr + 1) * len(allowed) // lw]
+            os.sched_setaffinity(0, share)
+            host["cores_pinned"] = len(share)
+    import torch
+    sys.setswitchinterval(args.switch_interval)
     ranks_seen = 1
     # DSVC_BENCH_FORCE_PG=1: build the process group even for ONE rank, so that init_process_group(nccl, device_id), barrier,
     # all_reduce(MAX) and the all_gather of the metric rows execute on RCCL on a 1-GPU box (tests/test_gpu_dropin.py)
@@ -164,9 +178,9 @@ def main():
         assert ranks_seen == args.gpus, f"process group has {ranks_seen} ranks, --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:           # N ranks share the host: keep each rank's torch CPU thread pool to its share of the cores
+    if world > 1:           # keep each rank's torch CPU thread pool to its share of the cores (the mask set above, or an even split)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 16)
-        torch.set_num_threads(max(1, cores // world))
+        torch.set_num_threads(max(1, cores if host["cores_pinned"] else cores // world))
 
     from deepsvc_amd import harness, ops, synth
     from deepsvc_amd.modules import pad
@@ -301,7 +315,11 @@ def main():
             al = sum(by[str(k)]["algorithmic_bytes_per_launch"] * c for k, c in hist.items() if c) / n
         else:
             tr, al = sec.get("hbm_bytes_per_launch_corrected"), sec.get("algorithmic_bytes_per_launch")
+        src_fp = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deepsvc_amd", "csrc", f), "rb").read() for f in ("conv3x3_pp.hip", "conv_mfma.hip", "conv_common.h"))).hexdigest()[:16]
+        stale = pmc.get("kernel_sources_sha256_16") not in (None, src_fp)
         return tr, {"traffic_over_algorithmic": tr / al if tr and al else None, "traffic_algorithmic_bytes": al,
+                    "traffic_pmc_collected_on": {"commit": pmc.get("commit"), "kernel_sources_sha256_16": pmc.get("kernel_sources_sha256_16")},
+                    "traffic_kernel_sources_now_sha256_16": src_fp, "traffic_pmc_is_stale": bool(stale) if pmc.get("kernel_sources_sha256_16") else None,
                     "traffic_source": f"{os.path.relpath(PMC_FILE, ROOT)} [{section}]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --lanes 1` "
                                       "(FETCH_SIZE x2 per MI355X_MICROARCH.md), bytes per launch by number of residual operands, weighted by this region's launch mix"}
 
@@ -366,7 +384,7 @@ def main():
                 h16 = lanes[0]
                 per = []
                 st = {"f16": (pad(h16["frames"][0], 64), None), "fp32": (pad(h16["frames"][0], 64), None)}
-                for t in (1, 2, 3):
+                for t in range(1, GOP):               # the WHOLE GOP: the error of frame t - 1 is an input of frame t (test_video.py:368-369)
                     cur, sm = pad(h16["frames"][t], 64), h16["sm"][t]
                     got = {}
                     for mode, L in (("f16", h16), ("fp32", f32)):
@@ -388,34 +406,38 @@ def main():
                 worst = lambda k: max((abs(p[k]) for p in per))
                 deltas = {"frames": per, "dbpp_pct": worst("dbpp_pct"), "dpsnr_db": worst("dpsnr_db"), "feature_rel_l2": worst("feature_rel_l2"),
                           "recon_rel_l2": worst("recon_rel_l2"),
-                          "note": "worst |delta| over 3 chained P-frames of lane 0's GOP, each mode chained on its own decoded state; "
+                          "note": f"worst |delta| over the {GOP - 1} chained P-frames of lane 0's GOP, each mode chained on its own decoded state; "
                                   "un-clamped reconstruction and decoded 64-channel feature; north_star tolerance: 1 % bpp, 0.05 dB"}
                 # ---- both modes against the REFERENCE's own run at this size (tests/golden/deepsvc_ref_1080p.npz: the reference's
                 #      compress()/decompress() on synth.make_frames(1088, 1920, 3), made in the build container) ----
-                gpath = os.path.join(ROOT, "tests", "golden", "deepsvc_ref_1080p.npz")
+                gpath = os.path.join(ROOT, "tests", "golden", "deepsvc_ref_gop1080p.npz")
                 if (H_pad, W_pad) == (1088, 1920) and os.path.exists(gpath):
                     import numpy as np
                     g = np.load(gpath)
-                    gfr = [f.to(dev) for f in synth.make_frames(1088, 1920, 3)]
+                    n_ref = int(g["g1080/psnr"].shape[0])
+                    gfr = [f.to(dev) for f in synth.make_frames(1088, 1920, n_ref + 1)]
                     vs = {}
                     for mode, L in (("fp32", f32), ("f16", h16)):
                         ops.set_precision(mode)
                         ref, feat, fr_rows = gfr[0], None, []
-                        for t in (1, 2):
+                        for t in range(1, n_ref + 1):
                             sm = synth.make_sm_fea(1088, 1920, t).to(dev)
                             mv, res = L["model"].compress(ref, gfr[t], sm, feat)
                             feat, recon, _, _ = L["model"].decompress(ref, mv, res, sm, feat)
-                            gold = [g[f"s1080/f{t}/enc/{c}_{k}"].tobytes() for c in ("mv", "res") for k in ("y", "z")]
                             mine = [e["strings"][i][0] for e in (mv, res) for i in (0, 1)]
-                            nb, ng = sum(len(x) for x in mine), sum(len(x) for x in gold)
-                            e_s, e_b, _ = PU.golden_full_errors(g, f"s1080/f{t}/dec/recon", recon)
-                            fr_rows.append({"frame": t, "bytes": nb, "bytes_reference": ng, "bytes_identical": mine == gold, "dbpp_pct": 100.0 * (nb - ng) / ng,
-                                            "dpsnr_db": PU.psnr(recon, gfr[t]) - float(g["s1080/psnr"][t - 1]),
+                            nb, ng = sum(len(x) for x in mine), int(g["g1080/string_bytes"][t - 1].sum())
+                            same = all(len(x) == int(g["g1080/string_bytes"][t - 1][k]) and zlib.crc32(x) == int(g["g1080/string_crc32"][t - 1][k]) for k, x in enumerate(mine))
+                            e_s, e_b, _ = PU.golden_full_errors(g, f"g1080/f{t}/dec/recon", recon)
+                            fr_rows.append({"frame": t, "bytes": nb, "bytes_reference": ng, "bytes_identical": same, "dbpp_pct": 100.0 * (nb - ng) / ng,
+                                            "dpsnr_db": PU.psnr(recon, gfr[t]) - float(g["g1080/psnr"][t - 1]), "psnr_reference_db": float(g["g1080/psnr"][t - 1]),
                                             "recon_rel_l2_samples": e_s, "recon_rel_l2_block_means": e_b})
                             ref = recon
                         vs[mode] = fr_rows
-                    deltas["vs_reference_golden"] = dict(vs, note="first + steady-state P-frame of the reference's own 1088x1920 run (clamped decoded frames, "
-                                                                  "strided samples and block means); asserted in tests/test_gpu_fullsize.py")
+                    deltas["vs_reference_golden"] = dict(vs, worst_f16_dbpp_pct=max(abs(r["dbpp_pct"]) for r in vs["f16"]),
+                                                         worst_f16_dpsnr_db=max(abs(r["dpsnr_db"]) for r in vs["f16"]),
+                                                         note=f"all {n_ref} P-frames of the reference's own 1088x1920 GOP (tests/golden/deepsvc_ref_gop1080p.npz: its "
+                                                              "compress()/decompress() chained on its own decoded state, test_video.py:332-369), each mode chained on ITS own "
+                                                              "decoded state; clamped decoded frames, strided samples and block means; asserted in tests/test_gpu_fullsize.py")
         finally:
             ops.set_precision(args.precision)
 
@@ -453,7 +475,8 @@ def main():
                                    + f"W0 synthetic PSNR weight set, compress+decompress per frame, GOPs sharded across ranks, {args.lanes} independent "
                                      f"GOP lane(s) in flight per GPU (one step = one frame on every lane)",
                        "precision": args.precision, "gop_lanes": args.lanes, "frames_per_step": args.lanes * world,
-                       "hbm_peak_gb": hbm_peak_gb, "hbm_steady_gb": hbm_steady_gb, "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
+                       "hbm_peak_gb": hbm_peak_gb, "hbm_steady_gb": hbm_steady_gb,
+                       "host": dict(host, torch_threads=torch.get_num_threads(), python_threads_alive=__import__("threading").active_count()), "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
                        "whole_frame_tflops": fps * FLOP_PER_PX[args.config] * H_pad * W_pad / 1e12 / world,
                        # the other legs of this run as scalars (details in the objects of the same names below)
                        "lanes1_fps": None if lanes1 is None else lanes1["value"],
@@ -482,6 +505,10 @@ def main():
                 line["cpu_baseline_small_sample"] = small
             line["cpu_baseline_1thread"] = cpu_baseline((args.cpu_sample, args.cpu_sample), args.cpu_frames, 1, H_pad, W_pad)
         print(json.dumps(line), flush=True)
+    # every rank says what it ran on (stderr: stdout carries only rank 0's JSON line)
+    import threading
+    sys.stderr.write(f"[bench rank {rank}/{world}] cores visible {host['cores_visible']}, pinned to {host['cores_pinned']}, torch threads {torch.get_num_threads()}, "
+                     f"python threads alive {threading.active_count()}, lanes {args.lanes}\n")
     if use_pg:
         import torch.distributed as dist
         dist.destroy_process_group()

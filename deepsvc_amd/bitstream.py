@@ -6,7 +6,10 @@ missing container so that encoder and decoder can live in different processes.  
 (they are byte-compatible with compressai 1.2.1's coder), so the container adds a fixed 8 + 12 * codecs bytes per frame
 (+ 4 per extra batch item) to the rate the harness reports:
 
-    frame   := magic "DSVC" | u8 version=1 | u8 type (0 = I, 1 = P) | u8 n_codecs | u8 reserved
+    frame   := magic "DSVC" | u8 version=1 | u8 type (0 = I, 1 = P) | u8 n_codecs | u8 flags
+    flags   := bits 0-1 arithmetic of the writer (0 = not stated, 1 = fp32 mode, 2 = f16 mode): the entropy parameters are floating-point
+               convolutions, so a stream decodes bit-exactly only with the arithmetic that wrote it (INTEGRATION.md, "Stream interchange");
+               bit 2 = payloads coded by the interleaved multi-stream range coder (FLAG_MULTISTREAM; 0 = compressai-compatible rANS)
                codec * n_codecs
     codec   := u16 shape_h | u16 shape_w | u32 len(y) | u16 n_z | u16 reserved | u32 len(z_i) * n_z | y | z_0 | z_1 ...
 
@@ -17,6 +20,8 @@ import struct
 MAGIC = b"DSVC"
 VERSION = 1
 TYPE_I, TYPE_P = 0, 1
+FLAG_MODE_MASK, FLAG_FP32, FLAG_F16, FLAG_MULTISTREAM = 0x3, 0x1, 0x2, 0x4
+MODE_FLAG = {"fp32": FLAG_FP32, "f16": FLAG_F16}
 
 
 class ContainerError(ValueError):
@@ -55,23 +60,39 @@ def _unpack_codec(buf, pos):
     return {"strings": [[y], zs], "shape": (h, w)}, pos
 
 
-def pack_frame(*encodings, frame_type=None):
-    """pack_frame(i_enc) for an I-frame, pack_frame(mv_enc, res_enc) for a P-frame -> bytes."""
+def pack_frame(*encodings, frame_type=None, flags=0):
+    """pack_frame(i_enc) for an I-frame, pack_frame(mv_enc, res_enc) for a P-frame -> bytes.
+    flags: e.g. MODE_FLAG[ops.get_precision()] so that a decoder in another process can refuse a stream of the other arithmetic."""
     if frame_type is None:
         frame_type = TYPE_I if len(encodings) == 1 else TYPE_P
     if not 1 <= len(encodings) <= 255:
         raise ContainerError("1..255 codecs per frame")
-    return MAGIC + struct.pack("<BBBB", VERSION, frame_type, len(encodings), 0) + b"".join(_pack_codec(e) for e in encodings)
+    if not 0 <= int(flags) <= 0x7:
+        raise ContainerError("unknown flag bits")
+    return MAGIC + struct.pack("<BBBB", VERSION, frame_type, len(encodings), int(flags)) + b"".join(_pack_codec(e) for e in encodings)
 
 
-def unpack_frame(buf):
-    """-> (frame_type, [encoding dict, ...]); raises ContainerError on a malformed or truncated frame."""
+def frame_flags(buf):
+    """The flags byte of a packed frame (see the module docstring)."""
+    buf = bytes(buf[:8])
+    if len(buf) < 8 or buf[:4] != MAGIC:
+        raise ContainerError("not a DSVC frame")
+    return buf[7]
+
+
+def unpack_frame(buf, expect_mode=None):
+    """-> (frame_type, [encoding dict, ...]); raises ContainerError on a malformed or truncated frame, and -- with expect_mode =
+    "fp32" | "f16" -- on a frame whose writer stated the OTHER arithmetic (a frame that states none is accepted)."""
     buf = bytes(buf)
     if len(buf) < 8 or buf[:4] != MAGIC:
         raise ContainerError("not a DSVC frame")
-    version, frame_type, n, _ = struct.unpack_from("<BBBB", buf, 4)
+    version, frame_type, n, flags = struct.unpack_from("<BBBB", buf, 4)
     if version != VERSION:
         raise ContainerError(f"unsupported container version {version}")
+    if flags & ~0x7:
+        raise ContainerError(f"unknown flag bits {flags:#x}")
+    if expect_mode is not None and (flags & FLAG_MODE_MASK) not in (0, MODE_FLAG[expect_mode]):
+        raise ContainerError(f"frame written in {'fp32' if flags & FLAG_MODE_MASK == FLAG_FP32 else 'f16'} mode, decoder runs {expect_mode}")
     pos, out = 8, []
     for _ in range(n):
         enc, pos = _unpack_codec(buf, pos)

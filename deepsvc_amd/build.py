@@ -81,7 +81,9 @@ def build(force=False, verbose=False, variant=None, defines=()):
         sp = os.path.join(CSRC, src)
         op = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(op)
-        if force or _stale(op, [sp] + HEADERS):
+        up = os.path.splitext(op)[0] + ".usage.json"
+        # (an object without its resource report -- or with an older one -- is recompiled: the scratch gate below must describe what ships)
+        if force or _stale(op, [sp] + HEADERS) or (src.endswith(".hip") and (not os.path.exists(up) or os.path.getmtime(up) < os.path.getmtime(op))):
             cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if src.endswith(".hip") else []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd), flush=True)
@@ -92,11 +94,21 @@ def build(force=False, verbose=False, variant=None, defines=()):
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         if src.endswith(".hip"):
+            usage = _resource_usage(out.decode(errors="replace"))
+            # the gate must not go inert: a compile whose remarks could not be parsed (wording change, remarks missing) is an error
+            broken = [k for k, v in usage.items() if min(v["scratch"], v["vgprs"], v["lds"]) < 0]
+            if not usage or broken:
+                raise RuntimeError(f"{src}: no usable -Rpass-analysis=kernel-resource-usage report "
+                                   f"({'no kernels parsed' if not usage else 'unparsed fields for ' + ', '.join(broken[:3])}): the scratch gate cannot vouch for this object")
             with open(os.path.splitext(op)[0] + ".usage.json", "w") as f:
-                json.dump(_resource_usage(out.decode(errors="replace")), f, indent=0, sort_keys=True)
+                json.dump(usage, f, indent=0, sort_keys=True)
     # No kernel of this library may touch scratch memory: a kernel that does has lost an array or its accumulators to the stack (once: the
     # generic conv's slab-epilogue variants, 3x slower, unnoticed by every parity test).  DSVC_ALLOW_SCRATCH=1 turns the check off.
-    spilled = {k: v["scratch"] for k, v in resource_usage(variant).items() if v["scratch"] > SCRATCH_ALLOWED.get(k, 0)}
+    usage_all = resource_usage(variant)
+    missing = [src for src in SOURCES if src.endswith(".hip") and not os.path.exists(os.path.join(obj_dir, os.path.splitext(src)[0] + ".usage.json"))]
+    if missing or not usage_all:
+        raise RuntimeError(f"no kernel resource report for {missing or SOURCES}: rebuild with --force")
+    spilled = {k: v["scratch"] for k, v in usage_all.items() if v["scratch"] > SCRATCH_ALLOWED.get(k, 0)}
     if spilled and variant is not None:          # diagnostic builds (probe registers) may spill a little: report only
         print("note: kernels using scratch memory in this diagnostic build: " + ", ".join(f"{k[28:70]}: {v}" for k, v in sorted(spilled.items())), flush=True)
     elif spilled and not os.environ.get("DSVC_ALLOW_SCRATCH"):

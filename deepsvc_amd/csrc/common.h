@@ -1,10 +1,13 @@
 // Shared host/device helpers of libdsvc (gfx950 only).
 #pragma once
+#ifndef DSVC_HOST_ONLY
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/dsvc.h"
 
+#ifndef DSVC_HOST_ONLY
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 // The 16-bit storage / MFMA operand type of the fast mode is IEEE binary16 (11-bit significand): with bfloat16 (8 bits) the
@@ -13,6 +16,7 @@ typedef _Float16 h16;
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
 
+#endif  // DSVC_HOST_ONLY
 // ---- error plumbing (api.cpp) ----------------------------------------------------------------
 void dsvc_set_error(const char* fmt, ...);
 #define DSVC_REQUIRE(cond, ...)                         \
@@ -22,6 +26,7 @@ void dsvc_set_error(const char* fmt, ...);
             return DSVC_E_ARG;                          \
         }                                               \
     } while (0)
+#ifndef DSVC_HOST_ONLY
 #define DSVC_CHECK_LAUNCH(what)                                                          \
     do {                                                                                 \
         hipError_t e_ = hipGetLastError();                                               \
@@ -31,6 +36,7 @@ void dsvc_set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
+#endif
 // ---- kernel-selection switches of dsvc_conv2d (dsvc_set_option, host_misc.cpp) ------------------
 struct DsvcOptions {
     int specialised, pp, ws, conv1x1, ws_waves4, ws_direct_store, tall_min_tiles, reg_epilogue, patch_prefetch, pp16, epi_f32, shuffle_vec, head, conv1x1_rows, small_pf;
@@ -42,6 +48,7 @@ enum { DSVC_CNT_GENERIC = 0, DSVC_CNT_PP, DSVC_CNT_WS, DSVC_CNT_CONV1X1, DSVC_CN
 extern long long g_dsvc_counters[DSVC_CNT_N];
 static inline void dsvc_count(int which) { __atomic_fetch_add(&g_dsvc_counters[which], 1, __ATOMIC_RELAXED); }
 
+#ifndef DSVC_HOST_ONLY
 // ---- f16 stores saturate ----------------------------------------------------------------------
 // MODE.FP16_OVFL (hwreg MODE bit 23): an overflowed f16 conversion result is clamped to +-65504 instead of becoming +-inf
 // (true infinities and NaNs pass through).  Every kernel that can store binary16 sets it first: a trained checkpoint whose
@@ -72,7 +79,9 @@ __device__ __forceinline__ void store_elem(void* p, int dtype, int64_t i, float 
     if (dtype == DSVC_F32) ((float*)p)[i] = v;
     else ((unsigned short*)p)[i] = f32_to_h16_bits(v);
 }
+#endif  // DSVC_HOST_ONLY
 static inline int dsvc_esize(int dtype) { return dtype == DSVC_F32 ? 4 : 2; }
+#ifndef DSVC_HOST_ONLY
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     switch (act) {
@@ -84,3 +93,4 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
         default: return v;
     }
 }
+#endif  // DSVC_HOST_ONLY

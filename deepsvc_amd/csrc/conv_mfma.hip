@@ -651,14 +651,6 @@ inline int chunk_elems(int compute) { return compute == DSVC_F32 ? 16 : 32; }
 
 }  // namespace
 
-extern "C" int64_t dsvc_conv_packed_bytes(int32_t Cout, int32_t nseg, const int32_t* segC, int32_t kh, int32_t kw, int32_t compute) {
-    if (Cout <= 0 || nseg < 1 || nseg > 3 || !segC || kh < 1 || kw < 1) return DSVC_E_ARG;
-    const int kce = chunk_elems(compute);
-    int64_t nch = 0;
-    for (int s = 0; s < nseg; ++s) nch += (segC[s] + kce - 1) / kce;
-    const int64_t Np = (Cout + 31) / 32 * 32;
-    return nch * kh * kw * Np * 64;
-}
 
 static int conv2d_impl(void* stream, const dsvc_conv_desc* d);
 

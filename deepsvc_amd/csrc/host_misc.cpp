@@ -42,7 +42,9 @@ extern "C" int dsvc_set_option(const char* key, int value) {
 }
 
 long long g_dsvc_counters[DSVC_CNT_N] = {0};
+extern long long g_dsvc_lut_overflow;      // rans_host.cpp
 extern "C" int64_t dsvc_get_counter(const char* key) {
+    if (key && strcmp(key, "lut_registry_overflow") == 0) return (int64_t)__atomic_load_n(&g_dsvc_lut_overflow, __ATOMIC_RELAXED);
     struct { const char* k; int i; } tab[] = {{"conv_generic", DSVC_CNT_GENERIC}, {"conv3x3_pp", DSVC_CNT_PP}, {"conv3x3_ws", DSVC_CNT_WS},
                                               {"conv1x1", DSVC_CNT_CONV1X1}, {"conv3x3_pp_fused_tail", DSVC_CNT_PP_POST}, {"conv_head", DSVC_CNT_HEAD}};
     for (auto& e : tab)
@@ -51,11 +53,13 @@ extern "C" int64_t dsvc_get_counter(const char* key) {
     return DSVC_E_ARG;
 }
 
+#ifndef DSVC_HOST_ONLY      // (DSVC_HOST_ONLY: the sanitizer build of the host functions, tests/native/ -- no HIP runtime, no device entry points)
 extern "C" int dsvc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
+#endif
 
 // compressai _CXX.pmf_to_quantized_cdf (ported there from ryg_rans) -- SURVEY.md Appendix A.4;
 // reached from the reference through update(): image_model.py:319-324, video_model.py:179-182.
@@ -90,6 +94,15 @@ static inline uint16_t f32_to_h16_host(float f) {  // IEEE binary16, round to ne
     const _Float16 h = (_Float16)f;
     uint16_t u; std::memcpy(&u, &h, 2);
     return u;
+}
+
+extern "C" int64_t dsvc_conv_packed_bytes(int32_t Cout, int32_t nseg, const int32_t* segC, int32_t kh, int32_t kw, int32_t compute) {
+    if (Cout <= 0 || nseg < 1 || nseg > 3 || !segC || kh < 1 || kw < 1) return DSVC_E_ARG;
+    const int kce = compute == DSVC_F32 ? 16 : 32;
+    int64_t nch = 0;
+    for (int s = 0; s < nseg; ++s) { if (segC[s] <= 0) return DSVC_E_ARG; nch += (segC[s] + kce - 1) / kce; }
+    const int64_t Np = (Cout + 31) / 32 * 32;
+    return nch * kh * kw * Np * 64;
 }
 
 // OIHW fp32 -> [chunk][tap][Np][64 B] of the compute type; chunks never straddle input segments.
@@ -155,6 +168,7 @@ extern "C" int dsvc_deconv5x5s2_to_conv3x3(const float* wt, const float* bias, i
 }
 
 
+#ifndef DSVC_HOST_ONLY
 // ---- one scan step = a recorded launch sequence, issued without returning to the host language (include/dsvc.h) ----------------
 extern "C" int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int32_t n_ops) {
     DSVC_REQUIRE(ops != nullptr && n_ops >= 0, "entropy_scan_step: null op list");
@@ -243,3 +257,4 @@ extern "C" int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int
 extern "C" int dsvc_pframe_segment_run(void* stream, const dsvc_scan_op* ops, int32_t n_ops) {
     return dsvc_entropy_scan_step(stream, ops, n_ops);       // same interpreter: a frame segment is a longer op list
 }
+#endif  // DSVC_HOST_ONLY

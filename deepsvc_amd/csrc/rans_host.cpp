@@ -19,8 +19,8 @@
 //     caller's dsvc_cdf_table (dsvc_cdf_build_lut); without one the decoder binary-searches.
 #include <cstdint>
 #include <cstring>
-#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 #include <algorithm>
 #include "common.h"
@@ -126,24 +126,49 @@ extern "C" int dsvc_rans_encoder_create(void** enc) {
 // array per call) and falls back to validating the rows when the pointer is unknown or the table behind it has changed.
 namespace {
 struct LutReg { const uint16_t* lut; uint64_t fp; };
-LutReg g_luts[64];
-std::atomic<int> g_nluts{0};
-std::mutex g_lut_mu;
-uint64_t table_fp(const dsvc_cdf_table* t) {
+constexpr int kMaxLuts = 256;        // 4 GOP lanes x (2 P-frame codecs + 1 I-frame codec) x 2 entropy models per rank = 24 live tables
+LutReg g_luts[kMaxLuts];
+int g_nluts = 0;
+std::shared_mutex g_lut_mu;          // readers: one shared lock per coder call; writers: build / forget
+// Fingerprint of the table a LUT was built for: its address and geometry, every row length, and EIGHT evenly spaced entries of every row
+// (+ the last one).  Contract (include/dsvc.h): a table is not modified while a LUT built for it is in use -- rebuild the LUT after
+// any change (the Python side does: entropy_models._EntropyModel.tables_changed drops the CdfTables object); the samples catch a buffer
+// that was recycled for another table.  Rows whose length is out of range make the table untrusted (nothing is read through them).
+bool table_fp(const dsvc_cdf_table* t, uint64_t* out) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)(uintptr_t)t->cdf); mix((uint64_t)t->rows); mix((uint64_t)t->stride);
-    for (int r = 0; r < t->rows; ++r) { mix((uint64_t)(uint32_t)t->cdf_length[r]); mix((uint64_t)(uint32_t)t->cdf[(int64_t)r * t->stride + t->cdf_length[r] / 2]); }
-    return h;
+    mix((uint64_t)(uintptr_t)t->cdf_length); mix((uint64_t)(uintptr_t)t->offset);
+    for (int r = 0; r < t->rows; ++r) {
+        const int32_t len = t->cdf_length[r];
+        if (len < 2 || len > t->stride) return false;
+        const int32_t* row = t->cdf + (int64_t)r * t->stride;
+        mix((uint64_t)(uint32_t)len); mix((uint64_t)(uint32_t)t->offset[r]);
+        for (int k = 0; k < 8; ++k) mix((uint64_t)(uint32_t)row[(int64_t)(len - 1) * k / 8]);
+        mix((uint64_t)(uint32_t)row[len - 1]);
+    }
+    *out = h;
+    return true;
 }
 bool lut_trusted(const dsvc_cdf_table* t) {
     if (!t->lut) return false;
-    const int n = g_nluts.load(std::memory_order_acquire);
-    for (int i = 0; i < n; ++i)
-        if (g_luts[i].lut == t->lut) return g_luts[i].fp == table_fp(t);
+    uint64_t fp;
+    if (!table_fp(t, &fp)) return false;
+    std::shared_lock<std::shared_mutex> lk(g_lut_mu);
+    for (int i = 0; i < g_nluts; ++i)
+        if (g_luts[i].lut == t->lut) return g_luts[i].fp == fp;
     return false;
 }
 }  // namespace
+
+long long g_dsvc_lut_overflow = 0;      // LUTs that found the registry full (dsvc_get_counter("lut_registry_overflow")): their tables are validated per call
+
+extern "C" int dsvc_cdf_forget_lut(const uint16_t* lut) {
+    std::unique_lock<std::shared_mutex> lk(g_lut_mu);
+    for (int i = 0; i < g_nluts; ++i)
+        if (g_luts[i].lut == lut) { g_luts[i] = g_luts[--g_nluts]; return 1; }
+    return 0;
+}
 
 extern "C" void dsvc_rans_encoder_destroy(void* enc) { delete (Encoder*)enc; }
 
@@ -156,8 +181,6 @@ extern "C" int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, 
     // validation hoisted out of the symbol loop: the table once, the indexes in one vectorisable pass
     // (a table that carries a LUT was validated row by row when dsvc_cdf_build_lut made it)
     if (!lut_trusted(t)) { if (int rc = rows_valid(t, "rans_encode")) return rc; }
-    for (int r = 0; r < t->rows; ++r)
-        DSVC_REQUIRE(t->cdf_length[r] >= 2 && t->cdf_length[r] <= t->stride, "rans_encode: cdf_length[%d] invalid", r);
     {
         uint32_t worst = 0;
         for (int64_t i = 0; i < n; ++i) worst |= (uint32_t)indexes[i] >= (uint32_t)t->rows ? 1u : 0u;
@@ -173,7 +196,7 @@ extern "C" int dsvc_rans_encode_with_indexes(void* enc, const int32_t* symbols, 
         const int32_t ci = indexes[i];
         const int32_t* row = cdf + (int64_t)ci * stride;
         const int32_t max_value = t->cdf_length[ci] - 2;
-        int32_t v = symbols[i] - t->offset[ci];
+        int32_t v = (int32_t)((uint32_t)symbols[i] - (uint32_t)t->offset[ci]);      // (wraps like the reference's int32 arithmetic, without UB)
         if (__builtin_expect((uint32_t)v < (uint32_t)max_value, 1)) {       // in-range symbol: one item, no escape
             const uint32_t start = (uint32_t)row[v];
             e->items[e->count++] = (start & 0xFFFFu) | (((uint32_t)row[v + 1] - start - 1u) << 16);
@@ -249,14 +272,14 @@ extern "C" int dsvc_cdf_build_lut(const dsvc_cdf_table* t, uint16_t* lut_out) {
     DSVC_REQUIRE(table_ok(t) && lut_out, "cdf_build_lut: bad argument");
     if (int rc = rows_valid(t, "cdf_build_lut")) return rc;
     {
-        std::lock_guard<std::mutex> lk(g_lut_mu);
-        int n = g_nluts.load(std::memory_order_relaxed), slot = -1;
-        for (int i = 0; i < n; ++i) if (g_luts[i].lut == lut_out) slot = i;
-        if (slot < 0 && n < 64) slot = n;
-        if (slot >= 0) {                   // (a 65th live LUT is simply not trusted: its table is validated per call)
-            g_luts[slot] = LutReg{lut_out, table_fp(t)};
-            if (slot == n) g_nluts.store(n + 1, std::memory_order_release);
-        }
+        uint64_t fp = 0;
+        const bool have_fp = table_fp(t, &fp);            // (rows_valid passed: always true)
+        std::unique_lock<std::shared_mutex> lk(g_lut_mu);
+        int slot = -1;
+        for (int i = 0; i < g_nluts; ++i) if (g_luts[i].lut == lut_out) slot = i;
+        if (slot < 0 && g_nluts < kMaxLuts) slot = g_nluts++;
+        if (slot >= 0 && have_fp) g_luts[slot] = LutReg{lut_out, fp};
+        else __atomic_fetch_add(&g_dsvc_lut_overflow, 1, __ATOMIC_RELAXED);     // not trusted: its table is validated on every call
     }
     for (int r = 0; r < t->rows; ++r) {
         const int32_t* row = t->cdf + (int64_t)r * t->stride;
@@ -294,11 +317,11 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
         if (worst)
             for (int64_t i = 0; i < n; ++i)
                 DSVC_REQUIRE(indexes[i] >= 0 && indexes[i] < t->rows, "rans_decode: cdf index %d out of range at %lld", indexes[i], (long long)i);
-        if (!lut_trusted(t)) { if (int rc = rows_valid(t, "rans_decode")) return rc; }
-        for (int r = 0; r < t->rows; ++r)
-            DSVC_REQUIRE(t->cdf_length[r] >= 2 && t->cdf_length[r] <= t->stride, "rans_decode: cdf_length[%d] invalid", r);
     }
-    const uint16_t* lut = t->lut;
+    // a LUT that dsvc_cdf_build_lut did not make for THIS table is not used at all (its entries index the rows): binary search instead
+    const bool trusted = lut_trusted(t);
+    if (!trusted) { if (int rc = rows_valid(t, "rans_decode")) return rc; }
+    const uint16_t* lut = trusted ? t->lut : nullptr;
     const int32_t* cdf = t->cdf;
     const int64_t stride = t->stride;
     const uint32_t* words = d->words.data();
@@ -339,11 +362,11 @@ extern "C" int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_
             uint32_t raw = 0;
             for (int32_t j = 0; j < nb && j < 8; ++j) raw |= d->bits() << (j * kBypassBits);
             v = (int32_t)(raw >> 1);
-            v = (raw & 1u) ? -v - 1 : v + max_value;
+            v = (raw & 1u) ? -v - 1 : (int32_t)((uint32_t)v + (uint32_t)max_value);       // (a forged escape may wrap; never UB)
             x = d->x; pos = d->pos;
             if (pos > nw + 2) { dsvc_set_error("rans_decode: stream exhausted at symbol %lld", (long long)i); return DSVC_E_RANGE; }
         }
-        out[i] = v + t->offset[ci];
+        out[i] = (int32_t)((uint32_t)v + (uint32_t)t->offset[ci]);
     }
     d->x = x; d->pos = pos;
     if (pos > nw + 2) { dsvc_set_error("rans_decode: stream exhausted within %lld symbols", (long long)n); return DSVC_E_RANGE; }

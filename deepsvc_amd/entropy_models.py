@@ -40,9 +40,13 @@ def _rows_to_cdf(pmf, tail_mass, pmf_length, max_length):
     return cdf
 
 
+_TABLE_GEN = [0]          # bumped whenever any entropy model's tables change (see _EntropyModel.tables_changed)
+
+
 class _EntropyModel(nn.Module):
     def __init__(self, likelihood_bound=1e-9):
         super().__init__()
+        self._table_gen = 0
         self.likelihood_lower_bound = _Bound(likelihood_bound)
         self.register_buffer("_offset", torch.IntTensor())
         self.register_buffer("_quantized_cdf", torch.IntTensor())
@@ -53,7 +57,17 @@ class _EntropyModel(nn.Module):
     quantized_cdf = property(lambda s: s._quantized_cdf)
     cdf_length = property(lambda s: s._cdf_length)
 
+    def tables_changed(self):
+        """The host / device tables of this model are about to differ from what any recording made so far has seen: recorded frame
+        programs (video_model.DeepSVC._segments) and scan programs freeze POINTERS to the device-side tables and would keep replaying
+        with the old ones while the host range coder already uses the new CDFs -- silently undecodable streams.  A process-wide
+        generation number, sampled into every invalidation fingerprint."""
+        _TABLE_GEN[0] += 1
+        self._table_gen = _TABLE_GEN[0]
+        self._host_tables = None
+
     def _store_tables(self, cdf, cdf_length, offset):
+        self.tables_changed()
         dev = self._offset.device
         self._quantized_cdf = torch.from_numpy(cdf).to(dev)
         self._cdf_length = torch.from_numpy(cdf_length.astype(np.int32)).to(dev)

@@ -435,7 +435,10 @@ class ChannelSplitICIP2020ResB(nn.Module):
         ps = self.__dict__.get("_fp_params")
         if ps is None:
             ps = self.__dict__["_fp_params"] = [p for p in self.parameters()]
-        return sum(p._version for p in ps) + (id(ps[0]) if ps else 0)
+        # (+ the table generations of the two entropy models: a direct gaussian_conditional.update_scale_table() / entropy_bottleneck.update()
+        #  replaces the device-side tables the recordings point to without touching a parameter)
+        return sum(p._version for p in ps) + (id(ps[0]) if ps else 0) + \
+            (self.entropy_bottleneck._table_gen << 20) + (self.gaussian_conditional._table_gen << 40)
 
     def _plan(self, B, h, w, device):
         key = (B, h, w, str(device), ops.RT.mode)
@@ -681,7 +684,9 @@ class ChannelSplitICIP2020ResB(nn.Module):
                 if key in state_dict:
                     cur = getattr(mod, n)
                     setattr(mod, n, torch.empty(state_dict[key].shape, dtype=cur.dtype, device=cur.device))
-            mod._host_tables = None
+            mod.tables_changed()
+            if hasattr(mod, "_dev_table"):
+                mod._dev_table = None
         self.__dict__.pop("_fp_params", None)      # parameters may be replaced objects afterwards
         self._epoch_ref()[0] += 1                  # recorded scan programs / graphs hold packed copies of the old weights
         return super().load_state_dict(state_dict, strict=strict)

@@ -134,16 +134,31 @@ class Arena:
     needs, not the sum.  Growing it re-patches the temporaries' pointers of every program registered with it."""
 
     def __init__(self):
-        self.buf, self.programs = None, []
+        self.buf, self.programs, self.streams = None, [], set()
 
     def attach(self, prog, nbytes, device):
         self.programs.append(prog)
         if self.buf is None or self.buf.numel() < nbytes:
+            if self.buf is not None and self.buf.is_cuda:
+                # the old workspace goes back to the caching allocator of the stream it was allocated on; replays may have used it from
+                # other streams (a caller that warms up on one stream and runs on another): nothing may still be reading it
+                torch.cuda.synchronize(self.buf.device)
             self.buf = torch.empty(max(nbytes, FrameProgram.ALIGN), dtype=torch.uint8, device=device)
+            self.streams = {_stream().value} if self.buf.is_cuda else set()       # (CPU tensors only in the host-logic tests)
             for p in self.programs:
                 p._patch_arena(self.buf.data_ptr())
         else:
             prog._patch_arena(self.buf.data_ptr())
+
+    def used_on_current_stream(self):
+        """Called by every replay: a workspace allocated on one stream and used on another must tell the caching allocator so
+        (record_stream), or its memory could be handed out again while a replay on the other stream is still running."""
+        if self.buf is None or not self.buf.is_cuda:
+            return
+        sid = _stream().value
+        if sid not in self.streams:
+            self.buf.record_stream(torch.cuda.current_stream(self.buf.device))
+            self.streams.add(sid)
 
 
 class FrameProgram:
@@ -263,6 +278,7 @@ class FrameProgram:
             bases.append(a.buf.data_ptr())
         for cell, slot, delta in self.ext_rel:
             cell.value = bases[slot] + delta
+        self._arena.used_on_current_stream()
         N.check(N.lib().dsvc_pframe_segment_run(_stream(), ctypes.addressof(self.arr), self.n), "pframe_segment_run")
         return fresh, self.persistent
 
@@ -866,6 +882,12 @@ class CdfTables:
         self.lut = np.empty((self.cdf.shape[0], 256), dtype=np.uint16)          # decode accelerator, owned here
         N.check(N.lib().dsvc_cdf_build_lut(byref(self.c), self.lut.ctypes.data), "cdf_build_lut")
         self.c.lut = self.lut.ctypes.data
+
+    def __del__(self):              # the registry entry must not outlive the LUT's memory (a recycled address would look registered)
+        try:
+            N.lib().dsvc_cdf_forget_lut(self.lut.ctypes.data)
+        except Exception:
+            pass
 
 
 def pack_small_inputs(acts, buf):

@@ -169,7 +169,12 @@ class DeepSVC(nn.Module):
         ps = self.__dict__.get("_fp_params")
         if ps is None:
             ps = self.__dict__["_fp_params"] = list(self.parameters())
-        fp = sum(p._version for p in ps)
+        # E1 / E2 inline the codecs' encoder scans (codec._step and its epoch check are bypassed inside a recording), so they freeze
+        # pointers to gaussian_conditional.device_table() and the entropy bottleneck's parameter blob: a table update (update(),
+        # update_scale_table(), load_state_dict) leaves the parameter versions alone and must drop the recordings too.  The table
+        # generation is not moved by weight packing, so sampling it here -- before any recording of this call -- is race-free.
+        fp = (sum(p._version for p in ps),) + tuple(m._table_gen for c in (self.mv_codec, self.res_codec)
+                                                     for m in (c.entropy_bottleneck, c.gaussian_conditional))
         cache = self.__dict__.setdefault("_frame_programs", {})
         if self.__dict__.get("_fp_seen") != fp:
             cache.clear()
@@ -177,7 +182,7 @@ class DeepSVC(nn.Module):
             # E1 / E2a / E2 / D1 / D2 run one after the other on the caller's stream and share one arena; DR runs beside D1 on the side stream
             self.__dict__["_arenas"] = (ops.Arena(), ops.Arena())
         sig = lambda t: (tuple(t.buf.shape), t.c0, t.C, t.code) if isinstance(t, Act) else \
-            (None if t is None else (tuple(t.shape), str(t.dtype), t.is_contiguous()))
+            (None if t is None else (tuple(t.shape), str(t.dtype), tuple(t.stride())))
         return cache, (str(ref.device), ops.RT.mode, ops.RT.compute, sig(ref)) + tuple(sig(t) for t in others)
 
     @torch.no_grad()

@@ -67,7 +67,7 @@ int dsvc_device_count(void);
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);
 /* Diagnostic: how many dsvc_conv2d launches each kernel family has taken since the library was loaded (process-wide).
- * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head".  Tests use it to prove that the
+ * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head"; "lut_registry_overflow" (see dsvc_cdf_build_lut).  Tests use it to prove that the
  * large-image kernels ran inside a frame that is checked against the reference.  Returns DSVC_E_ARG for an unknown key. */
 int64_t dsvc_get_counter(const char* key);
 /* Diagnostic: time every dsvc_conv2d launch of ONE shape (single-segment k x k conv, `stride`, C -> Cout channels on an H x W input) with
@@ -337,8 +337,15 @@ typedef struct dsvc_cdf_table {
                                   every row: starts at 0, strictly increasing, ends at 65536), or NULL -- then the coder
                                   validates the rows itself on every call */
 } dsvc_cdf_table;
-/* lut_out[row*256 + b] = largest symbol s with cdf[row][s] <= (b << 8): the decoder starts its search there */
+/* lut_out[row*256 + b] = largest symbol s with cdf[row][s] <= (b << 8): the decoder starts its search there.
+ * Validates every row and registers (lut_out -> fingerprint of the table) so that coder calls carrying this LUT skip the per-call
+ * validation.  Contract: the table is not modified while the LUT is in use (rebuild the LUT after any change; a fingerprint of the
+ * geometry and of nine entries per row catches recycled buffers, not adversarial in-place edits).  A LUT the library did not build
+ * for the table it arrives with is ignored (binary search + per-call validation).  The registry holds 256 LUTs; beyond that
+ * dsvc_get_counter("lut_registry_overflow") counts tables that fell back to per-call validation. */
 int dsvc_cdf_build_lut(const dsvc_cdf_table* t, uint16_t* lut_out);
+/* Drop a LUT from the registry before its memory is freed (returns 1 if it was registered, 0 otherwise). */
+int dsvc_cdf_forget_lut(const uint16_t* lut);
 
 /* BufferedRansEncoder (image_model.py:221,253-254) */
 int dsvc_rans_encoder_create(void** enc);

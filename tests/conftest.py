@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
+    config.addinivalue_line("markers", "slow: a CPU test that takes about a minute (full-size oracle frames); part of the default CPU suite")
 
 
 @pytest.fixture(scope="session")

@@ -9,7 +9,14 @@ make_golden.py) at the sizes the performance numbers are quoted on:
                           (ping-pong 3x3, weight-stationary 3x3, direct 1x1, fused ResBottleneck tail) in f16 mode; three
                           chained P-frames.
 
-    python tests/golden/make_golden_full.py [1080p] [256x1024]
+  deepsvc_ref_gop_1080p.npz / deepsvc_ref_gop_256x1024.npz   WHOLE GOPs chained on the reference's own decoded state exactly as
+                          test_video.py:332-369 chains them: 6 P-frames at 1088x1920 (GOP = 7, BASELINE.json config 2) and 11 P-frames at
+                          256x1024 (GOP = 12, config 3's chain length).  Lean per-frame records: the four string lengths + CRC-32
+                          (256x1024: the strings themselves too), PSNR, strided samples + block means + fp64 sums of recon / warped /
+                          predict, the carried feature of the last frame.  The first frames of these chains ARE the frames of the two
+                          files above (same seeds): the generator asserts that its strings equal the committed ones.
+
+    python tests/golden/make_golden_full.py [1080p] [256x1024] [gop1080p] [gop256x1024]
 
 Build-container only (about 15 minutes of CPU for the 1080p file).  Nothing of the reference is copied: only byte
 strings, line checksums of the symbol / index planes the reference's compress() handed to its range coder, and
@@ -150,6 +157,47 @@ def p_frames(ref_model, H, W, n_p, out, tag, stride3, stride64, blk3, blk64, fea
     out[f"{tag}/ref_threads"] = np.asarray([torch.get_num_threads()], dtype=np.int64)
 
 
+def gop_frames(ref_model, H, W, n_p, out, tag, stride3, blk3, stride64, blk64, keep_strings, anchor):
+    """A whole GOP through the reference's compress()/decompress() (video_model.py:137-167) chained as test_video.py:332-369 does
+    (ref_frame <- clamped recon, feature <- feature).  `anchor`: (npz of the short fixture, its tag, frames it holds)."""
+    frames = synth.make_frames(H, W, n_p + 1)
+    ref_frame, feature = frames[0], None
+    psnrs, times, lens, crcs = [], [], [], []
+    with torch.no_grad():
+        for t in range(1, n_p + 1):
+            sm = synth.make_sm_fea(H, W, t)
+            t0 = time.time()
+            mv, res = ref_model.compress(ref_frame, frames[t], sm, feature)
+            t1 = time.time()
+            feature, recon, warped, predict = ref_model.decompress(ref_frame, mv, res, sm, feature)
+            t2 = time.time()
+            times.append((t1 - t0, t2 - t1))
+            strs = [mv["strings"][0][0], mv["strings"][1][0], res["strings"][0][0], res["strings"][1][0]]      # mv_y, mv_z, res_y, res_z
+            lens.append([len(s) for s in strs])
+            crcs.append([zlib.crc32(s) for s in strs])
+            if anchor is not None and t <= anchor[2]:
+                g, atag = anchor[0], anchor[1]
+                for nm, s in zip(("mv_y", "mv_z", "res_y", "res_z"), strs):
+                    assert g[f"{atag}/f{t}/enc/{nm}"].tobytes() == s, f"{tag} f{t} {nm}: differs from the committed short fixture"
+            if keep_strings:
+                for nm, s in zip(("mv_y", "mv_z", "res_y", "res_z"), strs):
+                    out[f"{tag}/f{t}/enc/{nm}"] = np.frombuffer(s, dtype=np.uint8)
+                out[f"{tag}/f{t}/enc/mv_shape"] = np.asarray(mv["shape"], dtype=np.int64)
+                out[f"{tag}/f{t}/enc/res_shape"] = np.asarray(res["shape"], dtype=np.int64)
+            for name, tns in (("recon", recon), ("warped", warped), ("predict", predict)):
+                compact_full(f"{tag}/f{t}/dec/{name}", tns, out, stride3, blk3)
+            if t == n_p:
+                compact_full(f"{tag}/f{t}/dec/feature", feature, out, stride64, blk64)
+            psnrs.append(-10.0 * float(torch.log10(((recon - frames[t]) ** 2).mean())))
+            print(f"{tag} frame {t}: reference compress {t1 - t0:.1f} s, decompress {t2 - t1:.1f} s, {sum(lens[-1])} B, {psnrs[-1]:.4f} dB", flush=True)
+            ref_frame = recon
+    out[f"{tag}/psnr"] = np.asarray(psnrs, dtype=np.float64)
+    out[f"{tag}/string_bytes"] = np.asarray(lens, dtype=np.int64)          # [frame, (mv_y, mv_z, res_y, res_z)]
+    out[f"{tag}/string_crc32"] = np.asarray(crcs, dtype=np.uint32)
+    out[f"{tag}/ref_seconds"] = np.asarray(times, dtype=np.float64)
+    out[f"{tag}/ref_threads"] = np.asarray([torch.get_num_threads()], dtype=np.int64)
+
+
 def load_ref(ref_model, prod):
     sd, ref_sd = prod.state_dict(), ref_model.state_dict()
     load = {k: v for k, v in sd.items() if k in ref_sd}
@@ -166,6 +214,17 @@ def main():
     torch.manual_seed(0)
     ref_model = vm.DeepSVC()
     load_ref(ref_model, synth.make_model("W0"))
+    for key, (H, W, n_p, tag, s3, b3, s64, b64, keep, short, stag, nshort) in {
+            "gop256x1024": (256, 1024, 11, "g256x1024", 8, 8, 8, 16, True, "deepsvc_ref_256x1024.npz", "s256x1024", 3),
+            "gop1080p": (1088, 1920, 6, "g1080", 16, 16, 32, 32, False, "deepsvc_ref_1080p.npz", "s1080", 2)}.items():
+        if key in what:
+            out = {}
+            sp = os.path.join(HERE, short)
+            anchor = (np.load(sp), stag, nshort) if os.path.exists(sp) else None
+            gop_frames(ref_model, H, W, n_p, out, tag, s3, b3, s64, b64, keep, anchor)
+            path = os.path.join(HERE, "deepsvc_ref_" + key + ".npz")
+            np.savez_compressed(path, **out)
+            print(os.path.basename(path), os.path.getsize(path) // 1024, "KiB", flush=True)
     if "256x1024" in what:
         out = {}
         p_frames(ref_model, 256, 1024, 3, out, "s256x1024", 8, 8, 8, 16, features_of=(3,))

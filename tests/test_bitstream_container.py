@@ -43,3 +43,21 @@ def test_malformed_frames_raise(mangle):
         blob += b"\x00"
     with pytest.raises(bs.ContainerError):
         bs.unpack_frame(bytes(blob))
+
+
+def test_flags_byte_states_the_writer_arithmetic():
+    """INTEGRATION.md "Stream interchange": the entropy parameters are floating-point convolutions, so a frame decodes bit-exactly only
+    with the arithmetic that wrote it; the container can say which one that was."""
+    mv, res = _enc(100, 4, (1, 1)), _enc(50, 4, (1, 1))
+    blob = bs.pack_frame(mv, res, flags=bs.MODE_FLAG["f16"])
+    assert bs.frame_flags(blob) == bs.FLAG_F16 and len(blob) == len(bs.pack_frame(mv, res))
+    assert bs.unpack_frame(blob, expect_mode="f16")[1] == [mv, res]
+    assert bs.unpack_frame(blob)[1] == [mv, res]                       # a decoder that does not ask is not refused
+    with pytest.raises(bs.ContainerError):
+        bs.unpack_frame(blob, expect_mode="fp32")
+    assert bs.unpack_frame(bs.pack_frame(mv, res), expect_mode="fp32")[1] == [mv, res]      # unstated mode: accepted
+    with pytest.raises(bs.ContainerError):
+        bs.pack_frame(mv, res, flags=0x80)
+    bad = bytearray(blob); bad[7] = 0x40
+    with pytest.raises(bs.ContainerError):
+        bs.unpack_frame(bytes(bad))

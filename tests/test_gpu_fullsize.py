@@ -41,6 +41,16 @@ def gwide():
     return np.load(os.path.join(GOLD, "deepsvc_ref_256x1024.npz"))
 
 
+@pytest.fixture(scope="module")
+def ggop1080():
+    return np.load(os.path.join(GOLD, "deepsvc_ref_gop1080p.npz"))
+
+
+@pytest.fixture(scope="module")
+def ggopwide():
+    return np.load(os.path.join(GOLD, "deepsvc_ref_gop256x1024.npz"))
+
+
 def _model(precision):
     from deepsvc_amd import ops, synth
     ops.set_precision(precision)
@@ -178,7 +188,8 @@ def test_1080p_fp32_against_reference(g1080):
         print(f"[parity] s1080 f1 {nm}: {b_g} B vs reference {b_r} B ({100.0 * (b_g - b_r) / b_r:+.4f} %); differing symbols {r['symbols']} / "
               f"indexes {r['indexes']} of {r['total']}; roots {[(k, kind, f'{m:.1e}') for k, kind, m in r['roots']]}; unexplained {len(r['unexplained'])}")
         assert not r["unexplained"], f"{nm}: differences that no fragile decision of the reference explains: {r['unexplained'][:5]}"
-        assert len(r["roots"]) <= 8 and r["symbols"] <= 0.005 * r["total"] and abs(b_g - b_r) <= 1e-4 * b_r
+        # observed on MI355X: ONE root per codec (margins 3.8e-7 / 4.8e-8), 18 / 65 differing symbols of 522 k / 783 k, +-4 bytes of 814 380
+        assert len(r["roots"]) <= 3 and r["symbols"] <= 2e-4 * r["total"] and abs(b_g - b_r) <= 5e-5 * b_r, (len(r["roots"]), r["symbols"], r["total"])
         assert enc["strings"][1] == want["strings"][1] and tuple(enc["shape"]) == want["shape"], f"{nm}: hyper-latent string differs"
         n_roots += len(r["roots"])
         if r["where"].any():              # the residual codec codes a picture predicted with this codec's output: its input differs around here
@@ -277,3 +288,77 @@ def test_1080p_intra_key_frame_against_reference(g1080):
                 assert abs(b_g - b_r) <= 0.01 * b_r and e_s <= 2e-2 and e_b <= 4e-3
     finally:
         ops.set_precision("fp32")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# WHOLE GOPs against the reference: test_video.py:332-369 chains 6 (GOP = 7) or 11 (GOP = 12) P-frames on
+# decoded state, so north_star's tolerances (|d bpp| <= 1 %, |d PSNR| <= 0.05 dB) have to hold at the LAST frame of the chain, in the
+# mode the headline rate is quoted in.  Fixtures: tests/golden/make_golden_full.py gop1080p / gop256x1024 (the reference's own
+# compress()/decompress() chained on its own decoded state; per frame: string lengths + CRC-32, PSNR, strided samples + block means of
+# the decoded frames, the carried feature after the last frame).
+# ------------------------------------------------------------------------------------------------------------
+def _gop_chain(g, tag, H, W, n_p, precision, bounds, bytes_tol, psnr_tol, want_identical_first=0):
+    """One precision mode on its OWN encode -> decode chain over the whole GOP against the reference's chain.  -> per-frame rows."""
+    from deepsvc_amd import ops, synth
+    import zlib
+    model = _model(precision)
+    rows = []
+    try:
+        fr = synth.make_frames(H, W, n_p + 1)
+        ref, feat = fr[0].to(DEV), None
+        ref_bytes, ref_crc = g[f"{tag}/string_bytes"], g[f"{tag}/string_crc32"]
+        for t in range(1, n_p + 1):
+            pre, sm, cur = f"{tag}/f{t}", synth.make_sm_fea(H, W, t).to(DEV), fr[t].to(DEV)
+            mv, res = model.compress(ref, cur, sm, feat)
+            out, _ = _decode(model, ref, mv, res, sm, feat)
+            assert all(bool(torch.isfinite(o.float()).all()) for o in out)
+            strs = [mv["strings"][0][0], mv["strings"][1][0], res["strings"][0][0], res["strings"][1][0]]
+            same = [len(s) == int(ref_bytes[t - 1][k]) and zlib.crc32(s) == int(ref_crc[t - 1][k]) for k, s in enumerate(strs)]
+            b_g, b_r = sum(len(s) for s in strs), int(ref_bytes[t - 1].sum())
+            p_g, p_r = PU.psnr(out[1].cpu(), fr[t]), float(g[f"{tag}/psnr"][t - 1])
+            errs = {name: PU.golden_full_errors(g, f"{pre}/dec/{name}", out[j]) for j, name in ((1, "recon"), (2, "warped"), (3, "predict"))}
+            if t == n_p:
+                errs["feature"] = PU.golden_full_errors(g, f"{pre}/dec/feature", out[0].float())
+            rows.append(dict(frame=t, bytes=b_g, bytes_ref=b_r, identical=all(same), dpsnr=p_g - p_r, psnr_ref=p_r,
+                             **{k: max(v[0], v[1]) for k, v in errs.items()}))
+            print(f"[parity] {tag} f{t} {precision} vs reference: bytes {b_g} vs {b_r} ({100.0 * (b_g - b_r) / b_r:+.4f} %, identical strings: {same}), "
+                  f"PSNR {p_g:.4f} vs {p_r:.4f} dB ({p_g - p_r:+.4f}); " + ", ".join(f"{k} {max(v[0], v[1]):.2e}" for k, v in errs.items()))
+            feat, ref = out[0], out[1]
+        for r in rows:
+            t = r["frame"]
+            if t <= want_identical_first:
+                assert r["identical"], f"{tag} f{t}: {precision} strings differ from the reference's"
+            assert abs(r["bytes"] - r["bytes_ref"]) <= bytes_tol * r["bytes_ref"], f"{tag} f{t}: {precision} {r['bytes']} B vs the reference's {r['bytes_ref']} B"
+            assert abs(r["dpsnr"]) <= psnr_tol, f"{tag} f{t}: PSNR {precision} {r['dpsnr']:+.4f} dB from the reference's"
+            for name in ("recon", "warped", "predict", "feature"):
+                if name in r:
+                    assert r[name] <= bounds[name], f"{tag} f{t}: {precision} {name} off the reference's by {r[name]:.2e} (> {bounds[name]:.1e})"
+    finally:
+        ops.set_precision("fp32")
+    return rows
+
+
+def test_gop12_256x1024_fp32_against_reference(ggopwide):
+    """fp32 mode over config 3's chain length (11 P-frames): byte-identical strings for as long as no sub-1e-6-margin decision of the
+    reference flips (observed: see the printed rows; the first three frames are asserted identical as in the short fixture), and in
+    any case rate within 1e-3, PSNR within 0.005 dB and the decoded frames within 5e-4 of the reference's at every frame."""
+    tight = dict(recon=5e-4, warped=5e-4, predict=5e-4, feature=5e-4)
+    rows = _gop_chain(ggopwide, "g256x1024", 256, 1024, 11, "fp32", tight, 1e-3, 0.005, want_identical_first=3)
+    print(f"[parity] g256x1024 fp32: strings identical to the reference's on frames {[r['frame'] for r in rows if r['identical']]}")
+
+
+def test_gop12_256x1024_f16_against_reference(ggopwide):
+    """f16 mode (the mode the headline rate is quoted in) through frame 11 of the chain: north_star's tolerances at EVERY frame."""
+    _gop_chain(ggopwide, "g256x1024", 256, 1024, 11, "f16", PU.F16_GOP_BOUNDS, 0.01, 0.05)
+
+
+def test_gop7_1080p_f16_against_reference(ggop1080):
+    """BASELINE.json config 2 as the reference runs it: 6 chained P-frames at 1088x1920, f16 mode, north_star's tolerances at EVERY frame."""
+    _gop_chain(ggop1080, "g1080", 1088, 1920, 6, "f16", PU.F16_GOP_BOUNDS, 0.01, 0.05)
+
+
+def test_gop7_1080p_fp32_against_reference(ggop1080):
+    """The same GOP in fp32 mode: a handful of sub-1e-6-margin decisions flip per frame at this size (test_1080p_fp32_against_reference
+    proves where they come from), so strings are compared by length: rate within 1e-4, PSNR within 0.005 dB, decoded tensors 5e-4."""
+    tight = dict(recon=5e-4, warped=5e-4, predict=5e-4, feature=5e-4)
+    _gop_chain(ggop1080, "g1080", 1088, 1920, 6, "fp32", tight, 1e-4, 0.005)

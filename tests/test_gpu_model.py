@@ -348,6 +348,46 @@ def test_weight_edit_invalidates_recorded_scan():
     assert torch.equal(again[1], base[1]) and torch.equal(again[0].float(), base[0].float())
 
 
+def test_table_update_on_a_warmed_model_invalidates_frame_programs():
+    """E1 / E2 inline the codecs' encoder scans and freeze pointers to gaussian_conditional.device_table(); update() with
+    another scale table on a WARMED model (parameter versions unchanged) must drop them -- otherwise the GPU keeps indexing with the old
+    table while the host range coder already uses the new CDFs.  Checked against a fresh model that only ever saw the new table, and
+    against the launch-by-launch path of the same model."""
+    from deepsvc_amd import ops, synth
+    from deepsvc_amd.modules import get_scale_table
+    for mode in ("fp32", "f16"):
+        ops.set_precision(mode)
+        try:
+            fr, sm = [f.to(DEV) for f in synth.make_frames(128, 128, 2)], synth.make_sm_fea(128, 128, 1).to(DEV)
+            other = get_scale_table(0.2, 128, 64)
+            m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+            for _ in range(3):               # warm: frame programs recorded, scan graphs captured
+                mv, res = m.compress(fr[0], fr[1], sm, None)
+                old = [dict(mv.items()), dict(res.items())]
+                m.decompress(fr[0], old[0], old[1], sm, None)
+            for codec in (m.mv_codec, m.res_codec):
+                assert codec.update(scale_table=other, force=True)
+            mv, res = m.compress(fr[0], fr[1], sm, None)
+            got = [dict(mv.items()), dict(res.items())]
+            out = m.decompress(fr[0], got[0], got[1], sm, None)
+            fresh = synth.make_model("W0")
+            for codec in (fresh.mv_codec, fresh.res_codec):
+                codec.update(scale_table=other, force=True)
+            fresh = fresh.to(DEV)
+            prev, ops.FRAME_PROGRAMS[0] = ops.FRAME_PROGRAMS[0], False       # launch by launch
+            try:
+                mv2, res2 = fresh.compress(fr[0], fr[1], sm, None)
+                want = [dict(mv2.items()), dict(res2.items())]
+                wout = fresh.decompress(fr[0], want[0], want[1], sm, None)
+            finally:
+                ops.FRAME_PROGRAMS[0] = prev
+            assert got[0]["strings"] == want[0]["strings"] and got[1]["strings"] == want[1]["strings"], f"{mode}: stale table in a replayed segment"
+            assert got[1]["strings"] != old[1]["strings"], "the other scale table did not change the residual stream: the test is vacuous"
+            assert torch.equal(out[1], wout[1]) and torch.equal(out[0].float(), wout[0].float())
+        finally:
+            ops.set_precision("fp32")
+
+
 def test_replayed_scan_equals_eager_issue():
     """The recorded scan step (one C call per segment) and the captured HIP graph replay the launches the eager path issues: staging
     symbols / indexes and y_hat are bit-identical between a model that never records (DSVC_NO_SCAN_STEP / DSVC_NO_GRAPHS behaviour)

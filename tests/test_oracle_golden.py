@@ -172,3 +172,30 @@ def test_oracle_reproduces_reference_bytes_at_256x1024():
         check_golden_full(g, f"s256x1024/f{t}/dec/predict", predict, 1e-5)
         ref = recon
     check_golden_full(g, "s256x1024/f3/dec/feature", feat, 1e-5)
+
+
+@pytest.mark.slow
+def test_oracle_reproduces_reference_bytes_at_1088x1920():
+    """The HEADLINE size (BASELINE.json config 2): the oracle's four byte strings of the first P-frame are the reference's own
+    (tests/golden/deepsvc_ref_1080p.npz: 325 032 + 22 032 + 434 068 + 33 248 bytes), and its decoded frame is the reference's.  This is what
+    lets bench.py quote the oracle as a CPU baseline "pinned byte for byte incl. 1088x1920" and what anchors every oracle-side
+    comparison at full size.  About 30 s at 8 threads, 75 s at 3 (compress + decompress of one frame); marked `slow`
+    (deselect with -m "not slow" when iterating)."""
+    import os
+    from oracle.codec import DeepSVCOracle
+    from parity_util import check_golden_full
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "deepsvc_ref_1080p.npz"))
+    o = DeepSVCOracle(synth.make_model("W0").state_dict())
+    o.update()
+    frames = synth.make_frames(1088, 1920, 2)
+    sm = synth.make_sm_fea(1088, 1920, 1)
+    with torch.no_grad():
+        mv, res = o.compress(frames[0], frames[1], sm, None)
+        for nm, enc in (("mv", mv), ("res", res)):
+            assert enc["strings"][0][0] == g[f"s1080/f1/enc/{nm}_y"].tobytes(), (nm, "y")
+            assert enc["strings"][1][0] == g[f"s1080/f1/enc/{nm}_z"].tobytes(), (nm, "z")
+            assert tuple(enc["shape"]) == tuple(g[f"s1080/f1/enc/{nm}_shape"])
+        feat, recon, warped, predict = o.decompress(frames[0], mv, res, sm, None)
+    check_golden_full(g, "s1080/f1/dec/recon", recon, 1e-5)
+    check_golden_full(g, "s1080/f1/dec/predict", predict, 1e-5)
+    check_golden_full(g, "s1080/f1/dec/feature", feat, 1e-5)

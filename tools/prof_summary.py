@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
-PRE = "r03"
+PRE = sys.argv[2] if len(sys.argv) > 2 else "r04"
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -192,6 +192,18 @@ if all(os.path.exists(p) for p in (pf, pw, ps)):
                             "hbm_bytes_per_launch_corrected": sum(e["hbm_bytes_per_launch_corrected"] * e["launches"] for e in entries) / n,
                             "algorithmic_bytes_per_launch": sum(e["algorithmic_bytes_per_launch"] * e["launches"] for e in entries) / n,
                             "by_residual_operands": by_nres(entries)}
+    # what these counters were collected ON: bench.py compares the hash with the kernel sources of the run that quotes the file
+    # (`roofline.traffic_pmc_is_stale`), so a kernel change without a re-collected PMC file shows in the bench line
+    import hashlib
+    import subprocess
+    csrc = os.path.join(ROOT, "deepsvc_amd", "csrc")
+    full["kernel_sources_sha256_16"] = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("conv3x3_pp.hip", "conv_mfma.hip", "conv_common.h"))).hexdigest()[:16]
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = subprocess.call(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "deepsvc_amd/csrc"]) != 0
+        full["commit"] = head + ("+uncommitted csrc changes" if dirty else "")
+    except Exception:
+        full["commit"] = None
     with open(os.path.join(OUT, f"{PRE}_dominant_kernel_pmc.json"), "w") as f:
         json.dump(full, f, indent=1)
     # traffic of every kernel, for the pass-count table of DESIGN.md
