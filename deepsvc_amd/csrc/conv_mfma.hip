@@ -28,6 +28,7 @@ int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const ds
 int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv_head_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv3x3_pps_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 #ifdef DSVC_PHASE_PROBE
 // Build with DSVC_BUILD_DEFINES=-DDSVC_PHASE_PROBE (deepsvc_amd/build.py) to get per-phase shader-clock totals of wave 0 of
@@ -832,6 +833,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     if (opt.specialised && opt.pp) {        // 64-channel f16 ResBlock family: two phase-skewed wave groups per CU
         const int rc = dsvc_conv3x3_pp_try((hipStream_t)stream, p, d);
         if (rc == DSVC_OK) dsvc_count(DSVC_CNT_PP);
+        if (rc != 1) return rc;
+    }
+    if (opt.specialised && opt.pps) {       // f16 3x3 convs with 3+ input chunks and 64 output channels: two wave groups, weights streamed per chunk
+        const int rc = dsvc_conv3x3_pps_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_PPS);
         if (rc != 1) return rc;
     }
     if (opt.specialised && opt.ws) {        // other large f16 3x3 convs with <= 64 input channels: LDS-resident weights

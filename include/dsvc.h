@@ -60,14 +60,16 @@ int dsvc_device_count(void);
  * 3x3 over 32 / 64 / 64+64 channels or 7x7 over 16 -- of large images as packed dot products on the vector ALU: 1 = the shapes where that
  * measured faster than the MFMA kernels, 2 = every covered shape, 0 = none), "conv1x1_rows" (1: the pointwise kernel reads and writes
  * whole pixel rows and transposes to the MFMA operand layout through LDS; 0: lanes address 32-byte pieces of 32 rows), "small_pf" (1: the
- * generic kernel's 4x32 / 8x32 x 32-channel variants prefetch the next channel chunk's input patch: small images, f16 storage).  Defaults come from
+ * generic kernel's 4x32 / 8x32 x 32-channel variants prefetch the next channel chunk's input patch: small images, f16 storage), "pps" (1: f16 3x3
+ * stride-1 convs over 3+ 32-channel input chunks with 64 output channels on >= 1024 tiles take the two-group kernel with weights streamed per
+ * chunk, csrc/conv3x3_pps.hip; 0: the general kernel).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
- * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF).
+ * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF, DSVC_NO_PPS).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);
 /* Diagnostic: how many dsvc_conv2d launches each kernel family has taken since the library was loaded (process-wide).
- * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head"; "lut_registry_overflow" (see dsvc_cdf_build_lut).  Tests use it to prove that the
+ * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head", "conv3x3_pps"; "lut_registry_overflow" (see dsvc_cdf_build_lut).  Tests use it to prove that the
  * large-image kernels ran inside a frame that is checked against the reference.  Returns DSVC_E_ARG for an unknown key. */
 int64_t dsvc_get_counter(const char* key);
 /* Diagnostic: time every dsvc_conv2d launch of ONE shape (single-segment k x k conv, `stride`, C -> Cout channels on an H x W input) with

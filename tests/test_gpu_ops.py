@@ -408,6 +408,46 @@ def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, 
     close_f16("register epilogue vs torch", reg, want)
 
 
+@pytest.mark.parametrize("segs,H,W,act", [
+    ((64, 64), 256, 1024, 0),        # fea_embd[0] (modules.py:401): four chunks, no activation, exactly 1024 tiles
+    ((64, 64), 250, 1000, 2),        # UNet.up_conv3's first conv (modules.py:262-277, LeakyReLU): ragged right / bottom tiles
+    ((64, 32), 256, 1024, 0),        # Reconstruction.first_conv (modules.py:322): three chunks (odd: the weight-buffer parity wraps)
+    ((64, 8), 264, 1056, 0),         # RefineNet.refine[0] (modules.py:307): an 8-channel packed segment = a chunk with one valid quarter
+    ((64, 64, 32), 256, 1024, 1),    # three segments, five chunks, ReLU
+])
+def test_streamed_weights_pp_kernel_matches_general_kernel(segs, H, W, act):
+    """csrc/conv3x3_pps.hip (two wave groups, weights streamed per 32-channel chunk through two LDS buffers) against the general kernel
+    on the same operands: the same MFMAs in the same order per output element, bias first -> EQUAL f16 results; and against torch on
+    f16-rounded operands at half an ulp.  The launch counter proves which kernel ran."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + W + act)
+    bf = torch.float16
+    ops.set_precision("f16")
+    was = ops.set_option("pps", 1)
+    try:
+        m = Conv2d(sum(segs), 64, 3, 1, 1).to(DEV)
+        xs = [torch.randn(1, c, H, W) for c in segs]
+        ins = [_act(x, bf) for x in xs]
+        kw = dict(act=act, slope=0.05, out_dtype=bf)
+        n0 = ops.get_counter("conv3x3_pps")
+        got = m.run(ins, **kw).nchw().float().cpu()
+        again = m.run(ins, **kw).nchw().float().cpu()
+        assert ops.get_counter("conv3x3_pps") == n0 + 2, "the streamed-weights kernel did not take this shape"
+        ops.set_option("pps", 0)
+        ref = m.run(ins, **kw).nchw().float().cpu()
+        assert ops.get_counter("conv3x3_pps") == n0 + 2
+    finally:
+        ops.set_option("pps", was)
+        ops.set_precision("fp32")
+    assert torch.equal(got, again), "not deterministic"
+    assert torch.equal(got, ref), f"streamed-weights and general kernel differ: max |d| = {float((got - ref).abs().max()):.3e} at {int((got != ref).sum())} elements"
+    w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
+    xb = torch.cat([x.to(bf).float() for x in xs], 1)
+    want = _torch_act(F.conv2d(xb, w, b, padding=1), act, 0.05)
+    close_f16("streamed-weights kernel vs torch", got, want)
+
+
 @pytest.mark.parametrize("segs,cout,k,stride,H,W,act,res", [
     ((128,), 128, 3, 1, 160, 320, 1, True),        # UNet bottleneck ResBlock shape class: four N-tiles per workgroup
     ((96,), 128, 5, 2, 512, 512, 0, False),        # stride 2 (even/odd column LDS layout) with four N-tiles

@@ -1,0 +1,33 @@
+"""The streamed-weights two-group conv (csrc/conv3x3_pps.hip) against the general kernel on the frame's multi-chunk 3x3 shapes, same process,
+alternating, HIP events around 20 back-to-back launches on random data.   python tools/bench_pps.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepsvc_amd import _native as N, ops
+from deepsvc_amd.modules import Conv2d
+
+dev = "cuda:0"
+ops.set_precision("f16")
+SHAPES = [((64, 64), 1088, 1920, 0), ((64, 64), 544, 960, 2), ((64, 32), 1088, 1920, 0), ((64, 8), 1088, 1920, 0)]
+for segs, H, W, act in SHAPES:
+    torch.manual_seed(0)
+    m = Conv2d(sum(segs), 64, 3, 1, 1).to(dev)
+    ins = [ops.Act(torch.randn((1, H, W, c), device=dev).to(torch.float16)) for c in segs]
+    out = ops.new_act(1, H, W, 64, torch.float16, dev)
+    flop = 2.0 * H * W * 64 * sum(segs) * 9
+    res = {}
+    for rnd in range(3):
+        for opt in (1, 0):
+            ops.set_option("pps", opt)
+            for _ in range(3):
+                m.run(ins, out, act=act, slope=0.01)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                m.run(ins, out, act=act, slope=0.01)
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(opt, []).append(e0.elapsed_time(e1) / 20 * 1e3)
+    ops.set_option("pps", 1)
+    a, b = min(res[1]), min(res[0])
+    print(f"3x3 {'+'.join(map(str, segs))} -> 64 @{H}x{W} act {act}: streamed-weights {a:7.1f} us ({flop / a / 1e6:6.0f} TFLOP/s = {flop / a / 1e6 / 2500:.3f} of peak)   "
+          f"general {b:7.1f} us ({flop / b / 1e6 / 2500:.3f})   rounds {['%.0f/%.0f' % (x, y) for x, y in zip(res[1], res[0])]}", flush=True)
