@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSVC_LIB") or os.path.join(HERE, "lib", "libdsvc.so")     # DSVC_LIB: an instrumented build (tools/phase_probe.py)
 
-ABI_VERSION = 2            # include/dsvc.h: DSVC_VERSION this binding was written against
+ABI_VERSION = 3            # include/dsvc.h: DSVC_VERSION this binding was written against
 F32, F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_SIGMOID, ACT_HALF_TANH = range(6)
 EW_COPY, EW_ADD, EW_SUB, EW_BLEND2, EW_BLEND3, EW_CLAMP01 = range(6)
@@ -127,6 +127,11 @@ SIGNATURES = {
     "dsvc_conv2d": (c_int, [c_void_p, POINTER(ConvDesc)]),
     "dsvc_entropy_scan_step": (c_int, [c_void_p, c_void_p, c_int32]),
     "dsvc_pframe_segment_run": (c_int, [c_void_p, c_void_p, c_int32]),
+    "dsvc_pframe_program_load": (c_int, [c_void_p, c_int64, c_int32, POINTER(c_void_p)]),
+    "dsvc_pframe_program_destroy": (None, [c_void_p]),
+    "dsvc_pframe_program_info": (c_int, [c_void_p, c_void_p]),
+    "dsvc_pframe_compress": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dsvc_pframe_decompress": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dsvc_warp_bilinear_border": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                           c_int32, c_int32, c_int32, c_int32]),
     "dsvc_upsample2x_bilinear": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float]),

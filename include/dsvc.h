@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSVC_VERSION 2   /* 2: binary16 (not bfloat16) is dtype code 1; scan ops, refine_aggregate, counters; f16 stores saturate */
+#define DSVC_VERSION 3   /* 3: frame-level program API (dsvc_pframe_program_*, dsvc_pframe_compress / _decompress), dsvc_cdf_forget_lut; 2: binary16 (not bfloat16) is dtype code 1; scan ops, refine_aggregate, counters; f16 stores saturate */
 
 /* error codes */
 #define DSVC_OK 0
@@ -323,6 +323,40 @@ int dsvc_entropy_scan_step(void* stream, const dsvc_scan_op* ops, int32_t n_ops)
  * the frame tensors into the array and makes ONE call per segment.  The library issues the segment's launches back to back on
  * `stream` (stream-ordered, no host synchronisation); results are those of the same ops issued one by one. */
 int dsvc_pframe_segment_run(void* stream, const dsvc_scan_op* ops, int32_t n_ops);
+
+/* The same boundary for a caller WITHOUT the Python layer: one call per P-frame, as the reference's harness makes them
+ * (test_video.py:342 `mv_out_enc, res_out_enc = p_model.compress(ref_frame, x_cur, sm[0], feature)` and :349
+ * `feature, x_hat, warped, predict = p_model.decompress(ref_frame, mv_out_enc, res_out_enc, sm[0], feature)`;
+ * video_model.py:137-151,153-167).  A PROGRAM BLOB -- written once by deepsvc_amd/export.py::export_pframe_program from a model whose
+ * weights were loaded and whose tables were built (update()) -- carries the recorded segments of both frame variants (first P-frame of a
+ * GOP: feature == NULL, modules.py:425-428; steady state) and of the decoder-scan levels with relocation lists, the packed weights, the
+ * scan-workspace and arena sizes and the integer CDF tables.  dsvc_pframe_program_load allocates everything on `device` (hipMalloc) and
+ * resolves the relocations; the handle is then good for any number of frames of that size and precision.  Not re-entrant: one handle per
+ * stream.  All frame tensors are DEVICE pointers in the reference's layouts:
+ *   ref, cur     float32 [1,3,H,W]   (NCHW, H x W = the padded frame size the blob was exported for: dsvc_pframe_program_info)
+ *   sm_fea       float32 [1,256,H/4,W/4]   (NCHW; the semantic layer's feature, test_video.py:336-338)
+ *   feature      the carried state of the previous frame exactly as dsvc_pframe_decompress wrote it (NHWC, [1,H,W,64] in the blob's storage
+ *                type: info.feature_bytes), or NULL for the first P-frame after a key frame (test_video.py:296-297,332)
+ *   recon, warped, predict   float32 [1,3,H,W], clamped to [0,1] (video_model.py:167); warped / predict may be NULL
+ * Byte strings (host memory): index 0 = motion y, 1 = motion z, 2 = residual y, 3 = residual z -- the reference's
+ * mv_out_enc["strings"][0][0], [1][0], res_out_enc["strings"][0][0], [1][0] (compressai 1.2.1 rANS format); capacities from
+ * info.string_cap (worst case).  The calls return when the strings are complete (compress) / when every launch has been queued on
+ * `stream` (decompress: the decoded tensors are stream-ordered). */
+typedef struct dsvc_pframe_program dsvc_pframe_program;
+typedef struct dsvc_pframe_info {
+    int32_t H, W;               /* padded frame size */
+    int32_t precision;          /* DSVC_F32 / DSVC_F16: the arithmetic the blob was recorded in */
+    int32_t reserved;
+    int64_t feature_bytes;      /* size of the carried feature state */
+    int64_t string_cap[4];      /* worst-case size of each byte string */
+} dsvc_pframe_info;
+int dsvc_pframe_program_load(const void* blob, int64_t nbytes, int32_t device, dsvc_pframe_program** out);
+void dsvc_pframe_program_destroy(dsvc_pframe_program* program);
+int dsvc_pframe_program_info(const dsvc_pframe_program* program, dsvc_pframe_info* info);
+int dsvc_pframe_compress(dsvc_pframe_program* program, void* stream, const float* ref, const float* cur, const float* sm_fea, const void* feature,
+                         uint8_t* const out[4], const int64_t cap[4], int64_t nbytes[4]);
+int dsvc_pframe_decompress(dsvc_pframe_program* program, void* stream, const float* ref, const uint8_t* const strings[4], const int64_t nbytes[4],
+                           const float* sm_fea, const void* feature, void* feature_out, float* recon, float* warped, float* predict);
 
 /* ------------------------------------------------------------------------------------------
  * HOST: integer CDF construction and the range coder (compressai 1.2.1 _CXX / ans; Appendix A.4/A.5)

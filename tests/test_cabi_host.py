@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/dsvc.h but not exported by libdsvc.so"
         assert n in N.SIGNATURES, f"{n} has no ctypes signature in deepsvc_amd/_native.py"
     assert set(N.SIGNATURES) == set(names)
-    assert L.dsvc_version() == N.ABI_VERSION == 2
+    assert L.dsvc_version() == N.ABI_VERSION == 3
 
 
 def test_conv_desc_ctypes_mirror_matches_the_header(tmp_path):
