@@ -43,11 +43,21 @@ __device__ __forceinline__ void ps_store16(rsrc_t r, unsigned off, uint4 v) {
 }
 __device__ __forceinline__ float ps_lrelu(float x, float slope) { return __builtin_amdgcn_fmed3f(x, x * slope, __builtin_inff()); }
 
-template <bool ACT>
+// CT = h16: f16 storage and MFMA (v_mfma_f32_32x32x16_f16), activation none / ReLU / LeakyReLU (ACT), no residuals (the shapes above).
+// CT = float [round 4]: fp32 storage and v_mfma_f32_32x32x2_f32 -- the PARITY mode's arithmetic -- over 16-channel chunks (64 bytes, so
+// every byte count above is unchanged): 64 -> 64 is four chunks, 64+64 -> 64 eight.  An M phase is then 288 MFMAs of 64 cycles (18 432
+// cycles against ~3 000 for everything else a group does per phase), so the schedule keeps one wave per SIMD on the matrix pipe all the
+// time and the epilogue has slack: pre-activation, activation and up to two fp32 residuals are RUN-TIME parameters and the residuals are
+// loaded where they are used.  Operation order per output element is the general kernel's (conv_mfma.hip + epilogue_vec): MFMAs by
+// (chunk, tap, 16-byte half, element), + bias, activation, + (res1 + res2) -- fp32 results are bit-identical to it, which is what keeps
+// the byte-identity tests against the reference green.
+template <typename CT, bool ACT>
 __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p, int ntiles, int iters, float act_slope) {
     DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MTW = 2, NT = 2;
+    constexpr bool F32 = sizeof(CT) == 4;
+    constexpr int KCE = CTraits<CT>::KCE, EPV = CTraits<CT>::EPV;     // channels per 64-byte chunk / per 16-byte vector
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wg = wave & 3, gtid = tid & 255;      // group, wave in group, thread in group
@@ -83,8 +93,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
         if (p.nseg > 2 && ch >= p.seg[2].chunk0) si = 2;
         const ConvSeg& sg = p.seg[si];
         const rsrc_t rin = make_rsrc(sg.ptr, sg.bytes);
-        const unsigned ldb = (unsigned)sg.ld * 2, cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
-        const bool cok = (ch - sg.chunk0) * 32 + q * 8 < sg.C;             // short chunk (C % 8 == 0): the tail reads zeros
+        const unsigned ldb = (unsigned)sg.ld * (unsigned)sizeof(CT), cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
+        const bool cok = (ch - sg.chunk0) * KCE + q * EPV < sg.C;          // short chunk (C % EPV == 0): the tail reads zeros
         const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;
 #pragma unroll
         for (int j = 0; j < PS_PFV; ++j) {
@@ -93,12 +103,25 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
             pf[j] = buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));
         }
     };
+    const float pre_sl = p.pre_act == DSVC_ACT_RELU ? 0.f : p.slope;
     auto store_chunk = [&](uint4 (&pf)[PS_PFV]) {
 #pragma unroll
         for (int j = 0; j < PS_PFV; ++j) {
             const int pix = (gtid >> 2) + 64 * j;
             if (pix >= PS_NPATCH) continue;
-            *(uint4*)(lds_a + pix * ROWB + q * 16) = pf[j];
+            uint4 v = pf[j];
+            if constexpr (F32) {
+                if (p.pre_act != DSVC_ACT_NONE) {        // ResBlock1's leading activation, exactly as the general kernel applies it while staging
+                    unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float f = __builtin_bit_cast(float, u[k]);
+                        u[k] = __builtin_bit_cast(unsigned, fmaxf(f, f * pre_sl));
+                    }
+                    v = make_uint4(u[0], u[1], u[2], u[3]);
+                }
+            }
+            *(uint4*)(lds_a + pix * ROWB + q * 16) = v;
         }
     };
     // ---- weight staging: half `g` of a chunk = rows [288 g, 288 g + 288), vector v = gtid + 256 j -> row v >> 2, quarter v & 3 ----
@@ -147,9 +170,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, bf[s2 % 3][n]),   // D[channel][pixel]
-                                                                         __builtin_bit_cast(h16x8, af[s2 % 3][m]), acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) {
+                    if constexpr (F32) {
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, af[s2 % 3][m]), b4 = __builtin_bit_cast(f32x4, bf[s2 % 3][n]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j], a4[j], acc[m][n], 0, 0, 0);   // D[channel][pixel]
+                    } else {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, bf[s2 % 3][n]),   // D[channel][pixel]
+                                                                             __builtin_bit_cast(h16x8, af[s2 % 3][m]), acc[m][n], 0, 0, 0);
+                    }
+                }
             asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));   // pin the accumulation order (conv3x3_pp.hip)
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -177,6 +207,65 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
       const unsigned lo_ = sw.x, hi_ = sw.y; (LO) = __builtin_bit_cast(float, lo_); (HI) = __builtin_bit_cast(float, hi_); }
 #define PS_SWAP16(X, Y, A, B)                                                                                       \
     { const v2u_t sw = __builtin_amdgcn_permlane16_swap((X), (Y), false, false); (A) = sw.x; (B) = sw.y; }
+    // ---- fp32 epilogue: lane (r, h) holds channels 32 N + 8 h .. +7 (v0) and 32 N + 16 + 8 h .. +7 (v1) of pixel r of tile row M ----
+    const rsrc_t rr1 = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? p.res1_bytes : p.out_bytes);
+    const rsrc_t rr2 = make_rsrc(p.res2 ? p.res2 : p.out, p.res2 ? p.res2_bytes : p.out_bytes);
+    const bool has_res = p.res1 != nullptr || p.res2 != nullptr;
+    // residual operands of one 32x32 accumulator tile: 2 x 2 16-byte loads per operand, all eight requested before the first is used
+    // (per half tile -- eight dependent round trips per tile pair -- the epilogue outlasted the partner group's M phase)
+    struct ResRegs { uint4 a[4], b[4]; };
+    auto tile_pos = [&](const TileOrg& t, int m, int n, bool valid, unsigned* pm, unsigned* opix, unsigned* c0) {
+        const int oy = t.oy0 + wg * MTW + m, ox = t.ox0 + r;
+        *pm = (valid && oy < p.Ho && ox < p.Wo) ? 0u : OOB;
+        *opix = (unsigned)((t.b * p.Ho + oy) * p.Wo + ox);
+        *c0 = (unsigned)(n * 32 + 8 * h);
+    };
+    auto res_issue = [&](const TileOrg& t, int m, int n, bool valid, ResRegs& R) {
+        unsigned pm, opix, c0;
+        tile_pos(t, m, n, valid, &pm, &opix, &c0);
+#pragma unroll
+        for (int P2 = 0; P2 < 2; ++P2) {
+            const unsigned cb = c0 + 16u * P2;
+            const unsigned e1 = ((opix * (unsigned)p.res1_ld + cb) * 4u) | pm | (p.res1 ? 0u : OOB);
+            const unsigned e2 = ((opix * (unsigned)p.res2_ld + cb) * 4u) | pm | (p.res2 ? 0u : OOB);
+            R.a[2 * P2] = buf_load16(rr1, e1); R.a[2 * P2 + 1] = buf_load16(rr1, e1 + 16u);
+            R.b[2 * P2] = buf_load16(rr2, e2); R.b[2 * P2 + 1] = buf_load16(rr2, e2 + 16u);
+        }
+    };
+    auto tile_f32 = [&](const TileOrg& t, const f32x16& a, int m, int n, bool valid, const ResRegs& R) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            PS_SWAP32(a[j], a[4 + j], v0[j], v0[4 + j])
+            PS_SWAP32(a[8 + j], a[12 + j], v1[j], v1[4 + j])
+        }
+        unsigned pm, opix, c0;
+        tile_pos(t, m, n, valid, &pm, &opix, &c0);
+#pragma unroll
+        for (int P2 = 0; P2 < 2; ++P2) {
+            float* v = P2 ? v1 : v0;
+            const unsigned cb = c0 + 16u * P2;
+            const float4 ba = *(const float4*)(lds_bias + cb), bb = *(const float4*)(lds_bias + cb + 4);
+            const float bq[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = v[j] + bq[j];
+                v[j] = p.act == DSVC_ACT_RELU ? (x > 0.f ? x : 0.f) : (p.act == DSVC_ACT_LRELU ? (x > 0.f ? x : x * p.slope) : x);
+            }
+            if (has_res) {              // + (res1 + res2), the general kernel's order (conv_common.h: epilogue_vec); an absent operand reads zeros
+                const uint4 f1a = R.a[2 * P2], f1b = R.a[2 * P2 + 1], f2a = R.b[2 * P2], f2b = R.b[2 * P2 + 1];
+                const unsigned u1[8] = {f1a.x, f1a.y, f1a.z, f1a.w, f1b.x, f1b.y, f1b.z, f1b.w}, u2[8] = {f2a.x, f2a.y, f2a.z, f2a.w, f2b.x, f2b.y, f2b.z, f2b.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float r1 = __builtin_bit_cast(float, u1[j]) + 0.f, r2 = __builtin_bit_cast(float, u2[j]) + 0.f;
+                    v[j] += r1 + r2;
+                }
+            }
+            const unsigned eo = ((opix * (unsigned)p.out_ld + cb) * 4u) | pm;
+            ps_store16(rout, eo, make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])));
+            ps_store16(rout, eo + 16u, make_uint4(__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])));
+        }
+    };
 #define PS_TILE(M, N)                                                                                               \
     {                                                                                                               \
         float v0[8], v1[8];                                                                                         \
@@ -255,12 +344,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
         lds_barrier();
         if (c == NCH - 1) {              // ---- epilogue of the finished tile (wave-uniform branch) ----
             const bool valid = tile_of(k) < ntiles;
-            unsigned o_out[MTW][2];
+            if constexpr (F32) {
+                ResRegs RA;              // (two sets -- the next tile's operands in flight behind the current one -- spilled: 256 VGPRs + 184 B of scratch)
+                if (has_res) res_issue(cur, 0, 0, valid, RA);
+                tile_f32(cur, acc[0][0], 0, 0, valid, RA);
+                if (has_res) res_issue(cur, 0, 1, valid, RA);
+                tile_f32(cur, acc[0][1], 0, 1, valid, RA);
+                if (has_res) res_issue(cur, 1, 0, valid, RA);
+                tile_f32(cur, acc[1][0], 1, 0, valid, RA);
+                if (has_res) res_issue(cur, 1, 1, valid, RA);
+                tile_f32(cur, acc[1][1], 1, 1, valid, RA);
+            } else {
+                unsigned o_out[MTW][2];
 #pragma unroll
-            for (int m = 0; m < MTW; ++m)
+                for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                for (int half = 0; half < 2; ++half) o_out[m][half] = row_off(cur, m, valid, half);
-            PS_TILE(0, 0) PS_TILE(0, 1) PS_TILE(1, 0) PS_TILE(1, 1)
+                    for (int half = 0; half < 2; ++half) o_out[m][half] = row_off(cur, m, valid, half);
+                PS_TILE(0, 0) PS_TILE(0, 1) PS_TILE(1, 0) PS_TILE(1, 1)
+            }
             c = 0; ++k;
             cur = org_of(k);
         } else {
@@ -284,11 +385,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
 #undef PS_SWAP32
 }
 
-template <bool ACT>
+template <typename CT, bool ACT>
 int launch_pps(hipStream_t st, const ConvParams& p, int ntiles, float act_slope) {
     const size_t lds = (size_t)2 * PS_WBYTES + (size_t)2 * PS_NPATCH * ROWB + (size_t)PS_NTN * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv3x3_pps_kernel<ACT>;
+    auto kern = conv3x3_pps_kernel<CT, ACT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
@@ -303,30 +404,40 @@ int launch_pps(hipStream_t st, const ConvParams& p, int ntiles, float act_slope)
     return DSVC_OK;
 }
 
-bool ps_vec16_ok(const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (ld % 8) == 0; }
+bool ps_vec16_ok(const void* ptr, int ld, int esz) { return ((uintptr_t)ptr & 15) == 0 && ((int64_t)ld * esz) % 16 == 0; }
 
 }  // namespace
 
 // returns 1 when the shape is not covered (the caller falls through to the general kernel), else DSVC_OK / error
 int dsvc_conv3x3_pps_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
-    if (d->compute != DSVC_F16 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
-    if (p_in.nchunks < 3 || p_in.nchunks > 16 || d->Cout != 64) return 1;
-    if (d->res1 || d->res2 || d->res1_scale || d->post_weight || d->pre_act != DSVC_ACT_NONE) return 1;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
+    if (p_in.nchunks < 3 || p_in.nchunks > 32 || d->Cout != 64 || d->res1_scale || d->post_weight) return 1;
+    const bool f32 = d->compute == DSVC_F32;
+    const int esz = f32 ? 4 : 2, epv = f32 ? 4 : 8, dt = f32 ? DSVC_F32 : DSVC_F16;
     for (int s = 0; s < p_in.nseg; ++s) {                          // every pixel's chunk row is an aligned run of 16-byte vectors
         const ConvSeg& sg = p_in.seg[s];
-        if (sg.dtype != DSVC_F16 || (sg.C % 8) != 0 || !ps_vec16_ok(sg.ptr, sg.ld)) return 1;
+        if (sg.dtype != dt || (sg.C % epv) != 0 || !ps_vec16_ok(sg.ptr, sg.ld, esz)) return 1;
     }
-    if (d->out_dtype != DSVC_F16 || !ps_vec16_ok(d->out, d->out_ld)) return 1;
-    float act_slope;
-    if (d->act == DSVC_ACT_NONE) act_slope = 1.f;
-    else if (d->act == DSVC_ACT_RELU) act_slope = 0.f;
-    else if (d->act == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f) act_slope = d->slope;
-    else return 1;
+    if (d->out_dtype != dt || !ps_vec16_ok(d->out, d->out_ld, esz)) return 1;
+    auto act_ok = [&](int a) { return a == DSVC_ACT_NONE || a == DSVC_ACT_RELU || (a == DSVC_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f); };
+    if (!act_ok(d->act) || !act_ok(d->pre_act)) return 1;
+    if (f32) {                                                     // fp32 (parity) mode: pre-activation and fp32 residuals are run-time parameters
+        if (!g_dsvc_opt.pps_f32) return 1;
+        if (d->res1 && (d->res1_dtype != DSVC_F32 || !ps_vec16_ok(d->res1, d->res1_ld, 4))) return 1;
+        if (d->res2 && (d->res2_dtype != DSVC_F32 || !ps_vec16_ok(d->res2, d->res2_ld, 4))) return 1;
+        // two residual operands: 16 dependent-latency loads per tile pair in the epilogue -- measured slower than the general kernel
+        // (1375 vs 1337 us, tools/bench_pps.py); forced by pps_f32 = 2 (tests)
+        if (d->res1 && d->res2 && g_dsvc_opt.pps_f32 < 2) return 1;
+    } else if (d->res1 || d->res2 || d->pre_act != DSVC_ACT_NONE) {
+        return 1;
+    }
     ConvParams p = p_in;
     p.tiles_x = (p.Wo + 31) / 32;
     p.tiles_y = (p.Ho + PS_TH - 1) / PS_TH;
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;          // pixel indices go through the 24-bit multiplier
     if (ntiles < 1024) return 1;                                   // small images: the general kernel's finer tiling fills the chip better
-    return d->act == DSVC_ACT_NONE ? launch_pps<false>(st, p, ntiles, 1.f) : launch_pps<true>(st, p, ntiles, act_slope);
+    if (f32) return launch_pps<float, false>(st, p, ntiles, 1.f);
+    const float act_slope = d->act == DSVC_ACT_NONE ? 1.f : (d->act == DSVC_ACT_RELU ? 0.f : d->slope);
+    return d->act == DSVC_ACT_NONE ? launch_pps<h16, false>(st, p, ntiles, 1.f) : launch_pps<h16, true>(st, p, ntiles, act_slope);
 }

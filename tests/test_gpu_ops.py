@@ -448,6 +448,52 @@ def test_streamed_weights_pp_kernel_matches_general_kernel(segs, H, W, act):
     close_f16("streamed-weights kernel vs torch", got, want)
 
 
+@pytest.mark.parametrize("segs,H,W,pre,act,nres", [
+    ((64,), 256, 1024, 0, 0, 0),          # plain 64 -> 64 (four 16-channel chunks)
+    ((64,), 250, 1000, 1, 1, 0),          # ResBlock1.conv1 of the ReLU blocks (modules.py:200-204): pre-activation + activation, ragged tiles
+    ((64,), 256, 1024, 2, 2, 0),          # ... of the LeakyReLU blocks
+    ((64,), 256, 1024, 0, 0, 1),          # ResBlock1.conv2: + x
+    ((64,), 264, 1056, 0, 0, 2),          # FeatureExtraction's last block (modules.py:361-374): + x + conv1(x)
+    ((64, 64), 256, 1024, 0, 2, 0),       # two segments, eight chunks, LeakyReLU
+    ((64, 4), 256, 1024, 0, 0, 1),        # a 4-channel segment = one valid quarter of a chunk (fp32 mode takes 3-channel frames unpacked: C % 4 != 0 stays general)
+])
+def test_streamed_weights_pp_kernel_fp32_is_bit_identical_to_the_general_kernel(segs, H, W, pre, act, nres):
+    """The fp32 instantiation of csrc/conv3x3_pps.hip -- the parity mode's arithmetic: v_mfma_f32_32x32x2_f32 over 16-channel chunks,
+    pre-activation / activation / up to two fp32 residuals as run-time parameters -- against the general kernel: EQUAL bits (same MFMA order
+    per output element, + bias, activation, + (res1 + res2)), so the byte-identity of fp32 mode with the reference is untouched; and
+    against torch fp32."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + W + 7 * pre + act + nres)
+    f32 = torch.float32
+    ops.set_precision("fp32")
+    was = ops.set_option("pps_f32", 2)                  # 2: also the two-residual variant (off by default: not faster)
+    try:
+        m = Conv2d(sum(segs), 64, 3, 1, 1).to(DEV)
+        xs = [torch.randn(1, c, H, W) for c in segs]
+        rs = [torch.randn(1, 64, H, W) for _ in range(nres)]
+        ins = [_act(x, f32) for x in xs]
+        kw = dict(pre_act=pre, act=act, slope=0.05, out_dtype=f32)
+        if nres >= 1:
+            kw["res1"] = _act(rs[0], f32)
+        if nres == 2:
+            kw["res2"] = _act(rs[1], f32)
+        n0 = ops.get_counter("conv3x3_pps")
+        got = m.run(ins, **kw).nchw().float().cpu()
+        assert ops.get_counter("conv3x3_pps") == n0 + 1, "the streamed-weights kernel did not take this fp32 shape"
+        ops.set_option("pps_f32", 0)
+        ref = m.run(ins, **kw).nchw().float().cpu()
+        assert ops.get_counter("conv3x3_pps") == n0 + 1
+    finally:
+        ops.set_option("pps_f32", was)
+    assert torch.equal(got, ref), f"fp32: streamed-weights and general kernel differ: max |d| = {float((got - ref).abs().max()):.3e} at {int((got != ref).sum())} elements"
+    xb = torch.cat([_torch_act(x, pre, 0.05) for x in xs], 1)
+    want = _torch_act(F.conv2d(xb, m.weight.detach().cpu(), m.bias.detach().cpu(), padding=1), act, 0.05)
+    for r in rs:
+        want = want + r
+    report_close("fp32 streamed-weights kernel vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("segs,cout,k,stride,H,W,act,res", [
     ((128,), 128, 3, 1, 160, 320, 1, True),        # UNet bottleneck ResBlock shape class: four N-tiles per workgroup
     ((96,), 128, 5, 2, 512, 512, 0, False),        # stride 2 (even/odd column LDS layout) with four N-tiles
