@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("DSVC_PRECISION", "f16"), choices=["fp32", "f16"])
     ap.add_argument("--size", default="1080x1920")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3], help="BASELINE.json configs[1] (GOP=7, key frame given) or configs[2] (GOP=12, I-frame codec)")
+    ap.add_argument("--coder", default="rans", choices=["rans", "rans_ms"],
+                    help="range coder of the y strings: rans = the reference's format (default, the headline); rans_ms = the GPU-decodable multi-stream "
+                         "coder, a LABELLED non-reference format (+3-4 %% bytes, no host round trips in the decode chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="headline leg only (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=256)
@@ -211,10 +214,12 @@ def main():
         ops.set_precision(precision)
         m = synth.make_model("W0")
         m.update(force=True)
+        m.set_coder(args.coder)
         im = None
         if intra:
             im = synth.make_icodec("W0")
             im.update(force=True)
+            im.coder = args.coder
             im = im.to(dev)
         seed = 1234 + rank * 16 + ln
         return {"model": m.to(dev), "imodel": im, "stream": torch.cuda.Stream(dev), "t": 0, "ref": None, "feature": None, "rows": [],
@@ -474,7 +479,8 @@ def main():
                                    + ("(key frame coded by ICIP2020ResB + 11 P-frames), " if intra else "(key frame given + 6 P-frames), ")
                                    + f"W0 synthetic PSNR weight set, compress+decompress per frame, GOPs sharded across ranks, {args.lanes} independent "
                                      f"GOP lane(s) in flight per GPU (one step = one frame on every lane)",
-                       "precision": args.precision, "gop_lanes": args.lanes, "frames_per_step": args.lanes * world,
+                       "precision": args.precision, "coder": args.coder + (" (the reference's bitstream format)" if args.coder == "rans" else " (NON-reference multi-stream format, labelled)"),
+                       "gop_lanes": args.lanes, "frames_per_step": args.lanes * world,
                        "hbm_peak_gb": hbm_peak_gb, "hbm_steady_gb": hbm_steady_gb,
                        "host": dict(host, torch_threads=torch.get_num_threads(), python_threads_alive=__import__("threading").active_count()), "bpp": summ["bpp"], "psnr_db": summ["ppsnr"],
                        "whole_frame_tflops": fps * FLOP_PER_PX[args.config] * H_pad * W_pad / 1e12 / world,

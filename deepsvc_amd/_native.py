@@ -163,6 +163,9 @@ SIGNATURES = {
     "dsvc_pmf_to_quantized_cdf": (c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     "dsvc_cdf_build_lut": (c_int, [POINTER(CdfTable), c_void_p]),
     "dsvc_cdf_forget_lut": (c_int, [c_void_p]),
+    "dsvc_rans_ms_slot_words": (c_int64, [c_int32]),
+    "dsvc_rans_ms_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, POINTER(CdfTable), c_void_p, c_int32, c_void_p, c_void_p]),
+    "dsvc_rans_ms_decode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, POINTER(CdfTable), c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsvc_rans_encoder_create": (c_int, [POINTER(c_void_p)]),
     "dsvc_rans_encoder_destroy": (None, [c_void_p]),
     "dsvc_rans_encode_with_indexes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, POINTER(CdfTable)]),

@@ -57,6 +57,14 @@ class _EntropyModel(nn.Module):
     quantized_cdf = property(lambda s: s._quantized_cdf)
     cdf_length = property(lambda s: s._cdf_length)
 
+    def device_tables(self, device):
+        """ops.DeviceCdfTables for the multi-stream coder (rebuilt when the tables change)."""
+        key = (str(device), self._table_gen)
+        cur = self.__dict__.get("_dev_cdf")
+        if cur is None or cur[0] != key:
+            cur = self.__dict__["_dev_cdf"] = (key, ops.DeviceCdfTables(self.host_tables(), device))
+        return cur[1]
+
     def tables_changed(self):
         """The host / device tables of this model are about to differ from what any recording made so far has seen: recorded frame
         programs (video_model.DeepSVC._segments) and scan programs freeze POINTERS to the device-side tables and would keep replaying
@@ -82,6 +90,53 @@ class _EntropyModel(nn.Module):
             self._host_tables = ops.CdfTables(self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(),
                                               self._offset.cpu().numpy())
         return self._host_tables
+
+
+# ---- multi-stream strings (csrc/rans_ms.hip; a LABELLED non-reference format: bitstream.FLAG_MULTISTREAM) -------------------------------------
+# string := "MSR1" | u32 n_levels | n_levels x {u32 n_symbols, u32 n_streams} | per level: u32 state[n_streams] | u16 words[n_streams] (+ pad to
+#           4 bytes) | u16 payload[sum words] (+ pad)        -- a level = one dependency level of the slice scan; stream t of a level codes its
+#           symbols t, t + n_streams, ... (plane order); all integers little-endian
+MS_MAGIC = b"MSR1"
+
+
+def ms_pack(levels):
+    """levels: [(n_symbols, states uint32[n_streams], lens uint16[n_streams], payload uint16[sum lens])] -> bytes."""
+    import struct
+    out = [MS_MAGIC, struct.pack("<I", len(levels))]
+    for n, st, ln, _ in levels:
+        out.append(struct.pack("<II", int(n), len(st)))
+    for _, st, ln, pay in levels:
+        assert int(ln.sum()) == len(pay)
+        out.append(np.ascontiguousarray(st, dtype="<u4").tobytes())
+        b = np.ascontiguousarray(ln, dtype="<u2").tobytes()
+        out.append(b + b"\0" * (-len(b) % 4))
+        b = np.ascontiguousarray(pay, dtype="<u2").tobytes()
+        out.append(b + b"\0" * (-len(b) % 4))
+    return b"".join(out)
+
+
+def ms_unpack(data):
+    """bytes -> [(n_symbols, states, lens, payload)] (numpy views); raises ValueError on a malformed string."""
+    import struct
+    data = bytes(data)
+    if len(data) < 8 or data[:4] != MS_MAGIC:
+        raise ValueError("not a multi-stream string")
+    n_levels, = struct.unpack_from("<I", data, 4)
+    if n_levels > 64 or len(data) < 8 + 8 * n_levels:
+        raise ValueError("multi-stream string: bad level count")
+    heads = [struct.unpack_from("<II", data, 8 + 8 * k) for k in range(n_levels)]
+    pos, out = 8 + 8 * n_levels, []
+    for n, ns in heads:
+        if ns == 0 or ns > max(n, 1) or pos + 4 * ns + 2 * ns > len(data):
+            raise ValueError("multi-stream string: truncated stream table")
+        st = np.frombuffer(data, dtype="<u4", count=ns, offset=pos); pos += 4 * ns
+        ln = np.frombuffer(data, dtype="<u2", count=ns, offset=pos); pos += 2 * ns + (-(2 * ns) % 4)
+        nw = int(ln.astype(np.int64).sum())
+        if pos + 2 * nw > len(data):
+            raise ValueError("multi-stream string: truncated payload")
+        pay = np.frombuffer(data, dtype="<u2", count=nw, offset=pos); pos += 2 * nw + (-(2 * nw) % 4)
+        out.append((n, st, ln, pay))
+    return out
 
 
 class EntropyBottleneck(_EntropyModel):

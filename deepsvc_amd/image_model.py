@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import _native as N
 from . import ops
-from .entropy_models import EntropyBottleneck, GaussianConditional
+from .entropy_models import EntropyBottleneck, GaussianConditional, ms_pack, ms_unpack
 from .modules import Conv2d, Deconv5x5s2, ResBottleneckBlock, conv, get_scale_table, subpel_conv3x3
 from .ops import Act, to_act
 
@@ -181,6 +181,12 @@ def _run_stack(stack, segments, out=None, hidden_act=N.ACT_GELU, hidden_slope=0.
 
 class ChannelSplitICIP2020ResB(nn.Module):
     _stack_act = (N.ACT_GELU, 0.01)      # activation between the convs of the cc_mean / cc_scale / lrp stacks
+    # Range coder of the y string: "rans" = compressai 1.2.1's format on the host (the reference's bitstream, image_model.py:253-254,273-274,288);
+    # "rans_ms" = the GPU-decodable multi-stream coder (csrc/rans_ms.hip): same symbols, same tables, another -- LABELLED --
+    # string layout (entropy_models.ms_pack); a level decodes in one launch between the scan kernels, the decode chain has no host round trip.
+    # The z string stays in the reference's format in both modes (32 k symbols, decoded before any GPU work of the chain).
+    coder = "rans"
+    ms_symbols_per_stream = 256
 
     def __init__(self, in_ch=3, N=192, out_ch=3):
         super().__init__()
@@ -582,6 +588,8 @@ class ChannelSplitICIP2020ResB(nn.Module):
         """Host half: the symbol / index planes leave the device through one async copy into pinned memory; the host range coder
         runs on a worker thread behind the copy's event, so the caller can keep queuing GPU work (synthesis transform, MC, ...).
         -> {"strings", "shape"} dict (a lazy PendingStrings when defer=True)."""
+        if self.coder == "rans_ms":
+            return self._enc_finish_ms(ws, defer)
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck
         nz, ny = ws.nz, ws.ny
         host = torch.empty(ws.staging.numel(), dtype=torch.int32, pin_memory=True)
@@ -603,6 +611,106 @@ class ChannelSplitICIP2020ResB(nn.Module):
         del self.__dict__["_pending_futures"][:-4]      # keep only the most recent few (older ones have long finished)
         pending = PendingStrings(future)
         return pending if defer else pending.result()
+
+    # ---- multi-stream coder (coder = "rans_ms") ------------------------------------------------------------------------
+    def _ms_layout(self, ws):
+        """Per dependency level: (first symbol of the level in the y plane, n symbols, n streams, slot words, stream base, slot-word base)."""
+        lay = ws.__dict__.get("_ms_layout")
+        if lay is None or lay[0] != self.ms_symbols_per_stream:
+            S, rows, sb, wb = int(self.ms_symbols_per_stream), [], 0, 0
+            for g in ws.groups:
+                n = len(g) * ws.ns
+                nst = -(-n // S)
+                sw = ops.rans_ms_slot_words(-(-n // nst))
+                rows.append((g[0] * ws.ns, n, nst, sw, sb, wb))
+                sb, wb = sb + nst, wb + nst * sw
+            i16 = lambda k, **kw: torch.empty(k, dtype=torch.int16, **kw)
+            bufs = dict(slots=i16(wb, device=ws.device), states=torch.empty(sb, dtype=torch.int32, device=ws.device), lens=i16(sb, device=ws.device))
+            lay = ws.__dict__["_ms_layout"] = (S, rows, bufs, sb, wb)
+        return lay
+
+    def _enc_finish_ms(self, ws, defer=False):
+        """Host half in multi-stream mode: the y symbols are range-coded ON THE DEVICE, level by level (one thread per stream); what leaves the
+        device is the z symbol plane (coded on the host in the reference's format) and the streams' states / lengths / word slots, which a
+        worker thread concatenates into the string."""
+        gc, eb = self.gaussian_conditional, self.entropy_bottleneck
+        nz, ny = ws.nz, ws.ny
+        _, rows, bufs, n_st, n_words = self._ms_layout(ws)
+        tab = gc.device_tables(ws.device)
+        for first, n, nst, sw, sb, wb in rows:
+            ops.rans_ms_encode(ws.staging[nz + first: nz + first + n], ws.staging[nz + ny + first: nz + ny + first + n], n, nst, tab,
+                               bufs["slots"][wb: wb + nst * sw], sw, bufs["states"][sb: sb + nst], bufs["lens"][sb: sb + nst])
+        h_z = torch.empty(nz, dtype=torch.int32, pin_memory=True)
+        h_states = torch.empty(n_st, dtype=torch.int32, pin_memory=True)
+        h_lens = torch.empty(n_st, dtype=torch.int16, pin_memory=True)
+        h_slots = torch.empty(n_words, dtype=torch.int16, pin_memory=True)
+        h_z.copy_(ws.staging[:nz], non_blocking=True)
+        h_states.copy_(bufs["states"], non_blocking=True)
+        h_lens.copy_(bufs["lens"], non_blocking=True)
+        h_slots.copy_(bufs["slots"], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        zB, zC, zH, zW = ws.z_hat.B, ws.z_hat.C, ws.z_hat.H, ws.z_hat.W
+
+        def encode():
+            done.synchronize()
+            z_strings = eb.encode_symbols(h_z.numpy(), zB, zC, zH, zW)
+            st, ln, sl = h_states.numpy().view(np.uint32), h_lens.numpy().view(np.uint16), h_slots.numpy().view(np.uint16)
+            levels = []
+            for first, n, nst, sw, sb, wb in rows:
+                l = ln[sb: sb + nst]
+                words = sl[wb: wb + nst * sw].reshape(nst, sw)
+                keep = np.arange(sw, dtype=np.int32)[None, :] >= (sw - l.astype(np.int32))[:, None]       # a stream = the LAST `len` words of its slot
+                levels.append((n, st[sb: sb + nst], l, words[keep]))
+            return {"strings": [[ms_pack(levels)], z_strings], "shape": (zH, zW)}
+
+        future = _CODER_POOL.submit(encode)
+        self.__dict__.setdefault("_pending_futures", []).append(future)
+        del self.__dict__["_pending_futures"][:-4]
+        pending = PendingStrings(future)
+        return pending if defer else pending.result()
+
+    def _dec_chain_ms(self, strings, shape, device):
+        """Decode chain in multi-stream mode: the string's stream tables and payload go to the device in ONE copy; every dependency level is
+        then [decode kernel (one thread per stream) -> dequantise + LRP + next level's nets], stream-ordered, with no host round trip."""
+        gc, eb = self.gaussian_conditional, self.entropy_bottleneck
+        h4, w4 = int(shape[0]), int(shape[1])
+        ws = self._plan(len(strings[1]), h4 * 4, w4 * 4, device)
+        S, rows, _, _, _ = self._ms_layout(ws)
+        levels = ms_unpack(strings[0][0])
+        if len(levels) != len(rows) or any(n != r[1] or len(st) != r[2] for (n, st, _, _), r in zip(levels, rows)):
+            raise ValueError("multi-stream string does not match this codec's level layout (symbols per stream: %d)" % S)
+        # one upload: per level [states u32 | word offsets u32 (n_streams + 1) | payload u16, padded to 4 bytes]
+        parts, meta, pos = [], [], 0
+        for n, st, ln, pay in levels:
+            off = np.zeros(len(st) + 1, dtype=np.uint32)
+            np.cumsum(ln.astype(np.uint32), out=off[1:])
+            b = st.astype("<u4").tobytes() + off.tobytes() + pay.tobytes()
+            b += b"\0" * (-len(b) % 16)
+            meta.append((pos, pos + 4 * len(st), pos + 4 * len(st) + 4 * len(off), len(pay)))
+            parts.append(b)
+            pos += len(b)
+        blob = b"".join(parts)
+        up = ws.__dict__.get("_ms_up")
+        if up is None or up[0].numel() < len(blob):
+            cap = max(len(blob) * 2, 1 << 16)
+            up = ws.__dict__["_ms_up"] = [torch.empty(cap, dtype=torch.uint8, pin_memory=True), torch.empty(cap, dtype=torch.uint8, device=device), None]
+        if up[2] is not None:
+            up[2].synchronize()                   # the previous frame's upload out of this pinned buffer has completed
+        up[0].numpy()[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+        up[1][:len(blob)].copy_(up[0][:len(blob)], non_blocking=True)
+        up[2] = torch.cuda.Event()
+        up[2].record()
+        ws.z_sym_host.numpy()[:] = eb.decode_symbols(strings[1], h4, w4).reshape(-1)
+        ws.z_sym.copy_(ws.z_sym_host, non_blocking=True)
+        steps = self._segments(ws)
+        self._step(ws, "dec0", steps["dec0"])
+        tab, base = gc.device_tables(device), up[1].data_ptr()
+        for k, (group, (first, n, nst, sw, sb, wb)) in enumerate(zip(ws.groups, rows)):
+            o_st, o_off, o_pay, n_words = meta[k]
+            ops.rans_ms_decode(ws.idx_dev[:n], n, nst, tab, base + o_st, base + o_off, base + o_pay, n_words, ws.sym_dev[:n])
+            self._step(ws, f"dec{k + 1}", steps[f"dec{k + 1}"])
+        return ws
 
     def run_compress(self, segments, want_x_hat=False, x_hat_dtype=None, defer=False):
         """-> ({"strings", "shape"} dict (lazy PendingStrings when defer=True), x_hat Act or None)."""
@@ -633,6 +741,8 @@ class ChannelSplitICIP2020ResB(nn.Module):
 
     def dec_chain(self, strings, shape, device):
         """strings -> y_hat in the scan workspace: host range decoder and scan kernels, level by level (one sync point per level)."""
+        if self.coder == "rans_ms":
+            return self._dec_chain_ms(strings, shape, device)
         gc, eb = self.gaussian_conditional, self.entropy_bottleneck
         h4, w4 = int(shape[0]), int(shape[1])
         B = len(strings[1])

@@ -890,6 +890,33 @@ class CdfTables:
             pass
 
 
+class DeviceCdfTables:
+    """Device copies of a validated host table (cdf, cdf_length, offset, lut) for the multi-stream coder (include/dsvc.h: dsvc_rans_ms_*)."""
+
+    def __init__(self, host, device):
+        self.host = host
+        self.cdf = torch.from_numpy(host.cdf).to(device)
+        self.cdf_length = torch.from_numpy(host.cdf_length).to(device)
+        self.offset = torch.from_numpy(host.offset).to(device)
+        self.lut = torch.from_numpy(host.lut.view(np.int16)).to(device)           # (torch has no uint16 arithmetic: the bytes are what matters)
+        self.c = N.CdfTable(self.cdf.data_ptr(), host.cdf.shape[0], host.cdf.shape[1], self.cdf_length.data_ptr(), self.offset.data_ptr(), self.lut.data_ptr())
+
+
+def rans_ms_slot_words(symbols_per_stream):
+    return N.check(N.lib().dsvc_rans_ms_slot_words(int(symbols_per_stream)), "rans_ms_slot_words")
+
+
+def rans_ms_encode(symbols, indexes, n, n_streams, dev_tables, slots, slot_words, states, lens):
+    """symbols / indexes: int32 device vectors (views); slots: int16 device [n_streams * slot_words]; states: int32 / lens: int16 device [n_streams]."""
+    N.check(N.lib().dsvc_rans_ms_encode(_stream(), symbols.data_ptr(), indexes.data_ptr(), int(n), int(n_streams), byref(dev_tables.c),
+                                        slots.data_ptr(), int(slot_words), states.data_ptr(), lens.data_ptr()), "rans_ms_encode")
+
+
+def rans_ms_decode(indexes, n, n_streams, dev_tables, states_ptr, offsets_ptr, payload_ptr, payload_words, symbols_out):
+    N.check(N.lib().dsvc_rans_ms_decode(_stream(), indexes.data_ptr(), int(n), int(n_streams), byref(dev_tables.c), states_ptr, offsets_ptr, payload_ptr,
+                                        int(payload_words), symbols_out.data_ptr()), "rans_ms_decode")
+
+
 def pack_small_inputs(acts, buf):
     """Copy (and cast) a run of small activations into consecutive channels of the zero-padded packed buffer `buf`."""
     c = 0

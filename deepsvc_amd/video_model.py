@@ -317,6 +317,12 @@ class DeepSVC(nn.Module):
     def res_aux_loss(self):
         return sum(m.loss() for m in self.res_codec.modules() if isinstance(m, EntropyBottleneck))
 
+    def set_coder(self, name):
+        """Range coder of both codecs' y strings: "rans" (the reference's format, default) or "rans_ms" (GPU-decodable multi-stream
+        coder, a labelled non-reference mode: image_model.ChannelSplitICIP2020ResB.coder)."""
+        assert name in ("rans", "rans_ms")
+        self.mv_codec.coder = self.res_codec.coder = name
+
     def update(self, force=False):
         updated = self.mv_codec.update(force=force)
         updated |= self.res_codec.update(force=force)

@@ -396,6 +396,23 @@ int dsvc_rans_decoder_create(void** dec, const uint8_t* data, int64_t nbytes);
 void dsvc_rans_decoder_destroy(void* dec);
 int dsvc_rans_decode_stream(void* dec, const int32_t* indexes, int64_t n, const dsvc_cdf_table* t, int32_t* out);
 
+/* ------------------------------------------------------------------------------------------
+ * DEVICE: multi-stream range coder -- a labelled, NON-reference-compatible coding of the same symbols with the same tables (SURVEY.md
+ * section 8f-2; csrc/rans_ms.hip).  The reference's format (one rANS state per string, image_model.py:253-254,273-274,288) forces a
+ * host round trip and a synchronisation at every dependency level of the decoder scan; here a level's symbols are dealt round-robin to
+ * n_streams independent 32-bit rANS streams (16-bit words), one GPU thread each, so a level decodes in ONE stream-ordered launch.
+ * `dev_table`: a dsvc_cdf_table whose four arrays (cdf, cdf_length, offset, lut -- the lut as dsvc_cdf_build_lut makes it) are DEVICE
+ * copies of a validated host table.  Plane order / index meaning as dsvc_rans_encode_with_indexes.
+ *   encode: stream t writes its words downwards from the end of slots[t * slot_words ..], reports its final state and word count;
+ *           slot_words >= dsvc_rans_ms_slot_words(ceil(n / n_streams)).  The caller concatenates the streams' words (host or device).
+ *   decode: states / word_offsets[n_streams + 1] (in 16-bit words from `payload`) per stream -> symbols_out[n].
+ * deepsvc_amd/entropy_models.py defines the string layout built around these (header, per-level states / lengths, payload). */
+int64_t dsvc_rans_ms_slot_words(int32_t symbols_per_stream);
+int dsvc_rans_ms_encode(void* stream, const int32_t* symbols, const int32_t* indexes, int64_t n, int32_t n_streams, const dsvc_cdf_table* dev_table,
+                        uint16_t* slots, int32_t slot_words, uint32_t* states, uint16_t* lens);
+int dsvc_rans_ms_decode(void* stream, const int32_t* indexes, int64_t n, int32_t n_streams, const dsvc_cdf_table* dev_table,
+                        const uint32_t* states, const uint32_t* word_offsets, const uint16_t* payload, int64_t payload_words, int32_t* symbols_out);
+
 #ifdef __cplusplus
 }
 #endif
