@@ -52,14 +52,67 @@ def load_calibration(path=CALIBRATION):
         return json.load(f)
 
 
+def structured_tensor(kind, shape, **kw):
+    """Procedurally generated conv weights of the synthetic I-frame set (tools/calibrate_icip.py): the four strided convs of g_a become
+    space-to-depth selections (so the latent holds the picture, decimated by two, in its first 192 channels), the four transposed convs of
+    g_s their inverses, the last one a x2 bilinear interpolation.  Nothing is stored: a kind name and a gain generate the tensor.
+      "s2d"      Conv2d [Cout, Cin, 5, 5], stride 2, pad 2: out channel k*4 + 2*dy + dx = in channel k at block position (dy, dx), k < n_in
+      "s2d_dec"  the last analysis conv: out channel k*4 + 2*dy + dx = in channel src(k) -- the channels whose finest-level offsets are (0, 0),
+                 i.e. the picture decimated by two -- times `gain`
+      "d2s"      ConvTranspose2d [Cin, Cout, 5, 5] (stride 2, pad 2, output_padding 1): out channel k at phase (py, px) = in channel k*4 + 2*py + px
+      "bilinear" ConvTranspose2d: out channel c = x2 bilinear interpolation of in channel c (c < n_in)"""
+    w = torch.zeros(shape, dtype=torch.float32)
+    n_in, gain = int(kw.get("n_in", 0)), float(kw.get("gain", 1.0))
+    if kind == "s2d":
+        for k in range(n_in):
+            for dy in range(2):
+                for dx in range(2):
+                    w[k * 4 + 2 * dy + dx, k, 2 + dy, 2 + dx] = gain
+    elif kind == "s2d_dec":
+        # channel layout after three exact space-to-depth convs: ch3 = ((c*4 + 2*dy1 + dx1)*4 + 2*dy2 + dx2)*4 + 2*dy3 + dx3; keep dy1 = dx1 = 0
+        k = 0
+        for c in range(3):
+            for dy2 in range(2):
+                for dx2 in range(2):
+                    for dy3 in range(2):
+                        for dx3 in range(2):
+                            src = ((c * 4) * 4 + 2 * dy2 + dx2) * 4 + 2 * dy3 + dx3
+                            k1 = ((c * 4 + 2 * dy2 + dx2) * 4) + 2 * dy3 + dx3          # so that three d2s steps bring it back: k1 -> k2 = k1 // 4 -> c
+                            for dy in range(2):
+                                for dx in range(2):
+                                    w[k1 * 4 + 2 * dy + dx, src, 2 + dy, 2 + dx] = gain
+                            k += 1
+        assert k == 48
+    elif kind == "d2s":
+        for k in range(n_in):
+            for py in range(2):
+                for px in range(2):
+                    w[k * 4 + 2 * py + px, k, 2 + py, 2 + px] = gain
+    elif kind == "bilinear":
+        k1 = torch.tensor([0.0, 0.5, 1.0, 0.5, 0.0])
+        for c in range(n_in):
+            w[c, c] = gain * torch.outer(k1, k1)
+    else:
+        raise KeyError(kind)
+    return w
+
+
 def apply_calibration(state_dict, calib):
     """calib["tensors"]: key -> {"mul": m, "add": a}: tensor <- tensor * m + a (a: scalar or one value per output channel),
-    or {"set": [...]}: the whole tensor (flattened).  Returns a modified copy."""
+    or {"set": [...]}: the whole tensor (flattened), or {"structured": {...}, "eps": e}: e * tensor + structured_tensor(...) (then mul / add
+    if present).  Returns a modified copy."""
     out = {k: v.clone() for k, v in state_dict.items()}
     for key, spec in calib["tensors"].items():
         if "set" in spec:
             out[key] = torch.tensor(spec["set"], dtype=out[key].dtype).reshape(out[key].shape)
             continue
+        if "structured" in spec:
+            st = dict(spec["structured"])
+            base = out[key] * float(spec.get("eps", 0.0))
+            if "eps_tail" in spec:                       # rows (output channels) from `start` on keep the seeded init times `value`: live, un-structured channels
+                start, value = spec["eps_tail"]
+                base[int(start):] = out[key][int(start):] * float(value)
+            out[key] = base + structured_tensor(st.pop("kind"), tuple(out[key].shape), **st)
         add = torch.as_tensor(spec.get("add", 0.0), dtype=out[key].dtype)
         out[key] = out[key] * float(spec.get("mul", 1.0)) + add
     return out

@@ -16,7 +16,7 @@ make_golden.py) at the sizes the performance numbers are quoted on:
                           predict, the carried feature of the last frame.  The first frames of these chains ARE the frames of the two
                           files above (same seeds): the generator asserts that its strings equal the committed ones.
 
-    python tests/golden/make_golden_full.py [1080p] [256x1024] [gop1080p] [gop256x1024]
+    python tests/golden/make_golden_full.py [1080p | icip1080] [256x1024] [gop1080p] [gop256x1024]
 
 Build-container only (about 15 minutes of CPU for the 1080p file).  Nothing of the reference is copied: only byte
 strings, line checksums of the symbol / index planes the reference's compress() handed to its range coder, and
@@ -231,15 +231,31 @@ def main():
         path = os.path.join(HERE, "deepsvc_ref_256x1024.npz")
         np.savez_compressed(path, **out)
         print(os.path.basename(path), os.path.getsize(path) // 1024, "KiB", flush=True)
-    if "1080p" in what:
-        out = {}
-        p_frames(ref_model, 1088, 1920, 2, out, "s1080", 16, 32, 16, 32, features_of=(1, 2))
+    if "1080p" in what or "icip1080" in what:
+        path = os.path.join(HERE, "deepsvc_ref_1080p.npz")
+        if "1080p" in what:
+            out = {}
+            p_frames(ref_model, 1088, 1920, 2, out, "s1080", 16, 32, 16, 32, features_of=(1, 2))
+        else:                 # "icip1080": only the key-frame part is regenerated (the P-frame arrays of the existing file are kept as they are)
+            old = np.load(path)
+            out = {k: old[k] for k in old.files if not k.startswith("icip1080/")}
         # one intra-coded key frame at the same size (config 3's I-frame codec)
         import image_model as ref_im  # noqa: the reference's module
         torch.manual_seed(0)
         icip = ref_im.ICIP2020ResB()
         load_ref(icip, synth.make_icodec("W0"))
         tap = Tap(icip.gaussian_conditional)
+        # the hyper-latent's rounding decisions too (image_model.py:510-511: z -> entropy_bottleneck.compress): a flipped z symbol moves the
+        # means / scales of every latent pixel inside the hyper-synthesis receptive field, so it is a ROOT of y-plane differences as well
+        zrec = {}
+        eb = icip.entropy_bottleneck
+        eb_compress = eb.compress
+
+        def eb_tap(z, *a, **kw):
+            zrec["z"] = z.detach().double()
+            return eb_compress(z, *a, **kw)
+
+        eb.compress = eb_tap
         x = synth.make_frames(1088, 1920, 1)[0]
         with torch.no_grad():
             tap.on = True
@@ -252,10 +268,20 @@ def main():
             t2 = time.time()
         print(f"icip 1080p: reference compress {t1 - t0:.1f} s, decompress {t2 - t1:.1f} s", flush=True)
         store_planes(out, "icip1080/enc/y", *planes)
+        eb.compress = eb_compress
+        med = eb._get_medians().detach().double().reshape(1, -1, 1, 1)
+        v = (zrec["z"] - med)[0]
+        zsym = torch.round(v)
+        zmargin = ((v - torch.floor(v)) - 0.5).abs()
+        assert float(zsym.abs().max()) < 32768
+        out["icip1080/enc/z_sym"] = zsym.numpy().astype(np.int16)
+        c, yy, xx = torch.nonzero(zmargin < SYM_MARGIN * (1.0 + v.abs()), as_tuple=True)
+        out["icip1080/enc/z_fragile"] = torch.stack([c.double(), yy.double(), xx.double(), zmargin[c, yy, xx], v.abs()[c, yy, xx]], 1).numpy().astype(np.float32)
         out["icip1080/enc/y"] = np.frombuffer(enc["strings"][0][0], dtype=np.uint8)
         out["icip1080/enc/z"] = np.frombuffer(enc["strings"][1][0], dtype=np.uint8)
         out["icip1080/enc/shape"] = np.asarray(enc["shape"], dtype=np.int64)
         compact_full("icip1080/dec/x_hat", dec["x_hat"], out, 16, 16)
+        out["icip1080/psnr"] = np.asarray([-10.0 * float(torch.log10(((dec["x_hat"] - x) ** 2).mean()))], dtype=np.float64)
         out["icip1080/ref_seconds"] = np.asarray([t1 - t0, t2 - t1])
         path = os.path.join(HERE, "deepsvc_ref_1080p.npz")
         np.savez_compressed(path, **out)

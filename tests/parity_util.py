@@ -155,12 +155,13 @@ def explain_plane_mismatches(g, pre, sym, idx, slice_depth, max_support, sym_tol
     frag_s = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) / (1.0 + float(r[4])) for r in fs}       # margin relative to 1 + |y| + |mu|
     frag_i = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) for r in fi}
     contaminated = np.zeros((h, w), dtype=bool) if seed is None else seed.copy()   # latent pixels where a support slice's y_hat (or the input) differs
-    roots, unexplained, n_sym, n_idx = [], [], 0, 0
+    roots, unexplained, n_sym, n_idx, checked_by_slice = [], [], 0, 0, []
     for i in range(M // slice_depth):
         c0 = i * slice_depth
         ms, mi = sym[c0:c0 + slice_depth] != ref_sym[c0:c0 + slice_depth], idx[c0:c0 + slice_depth] != ref_idx[c0:c0 + slice_depth]
         n_sym, n_idx = n_sym + int(ms.sum()), n_idx + int(mi.sum())
         both = ms | mi
+        checked_by_slice.append(1.0 - float(_dilate(contaminated, param_radius).mean()))      # share of the map held to "identical, or a listed root" in this slice
         if both.any():
             zone = _dilate(contaminated, param_radius)
             for c, y, x in zip(*np.nonzero(both & ~zone[None])):
@@ -175,7 +176,29 @@ def explain_plane_mismatches(g, pre, sym, idx, slice_depth, max_support, sym_tol
             contaminated = _dilate(contaminated, radius) | both.any(0)
     lines = int((line_crcs(sym) != line_crcs(ref_sym)).sum()), int((line_crcs(idx) != line_crcs(ref_idx)).sum())
     where = ((sym != ref_sym) | (idx != ref_idx)).any(0)
-    return dict(symbols=n_sym, indexes=n_idx, total=int(sym.size), roots=roots, unexplained=unexplained, lines=lines, where=where)
+    # how much of the latent map the walk could still hold to "identical or a listed root" at the LAST level (the power of the check)
+    return dict(symbols=n_sym, indexes=n_idx, total=int(sym.size), roots=roots, unexplained=unexplained, lines=lines, where=where,
+                strictly_checked=checked_by_slice)
+
+
+def explain_hyper_mismatches(g, pre, zsym, y_shape, tol=2e-5, reach=8):
+    """The GPU encoder's HYPER-latent symbols [N, h/4, w/4] against the reference's (`<pre>z_sym` + `<pre>z_fragile` of
+    tests/golden/make_golden_full.py): a differing z symbol must be a rounding decision the reference took within `tol` (relative to
+    1 + |z|) of flipping -- a z ROOT.  Its z_hat feeds both hyper-synthesis nets (two transposed 5x5 stride-2 convs and a 3x3 conv,
+    image_model.py:384-398: a z pixel reaches +-7 latent pixels around its 4x4 footprint), so it seeds y-plane differences there.
+    -> dict(roots [(key, margin)], unexplained [...], seed bool [h, w] for explain_plane_mismatches)"""
+    ref = g[pre + "z_sym"].astype(np.int32)
+    zsym = np.asarray(zsym, dtype=np.int32).reshape(ref.shape)
+    frag = {(int(r[0]), int(r[1]), int(r[2])): float(r[3]) / (1.0 + float(r[4])) for r in g[pre + "z_fragile"]}
+    h, w = y_shape
+    seed = np.zeros((h, w), dtype=bool)
+    roots, unexplained = [], []
+    for c, y, x in zip(*np.nonzero(zsym != ref)):
+        key = (int(c), int(y), int(x))
+        m = frag.get(key)
+        (roots if m is not None and m <= tol else unexplained).append((key, m))
+        seed[max(4 * y - reach, 0):4 * y + 4 + reach, max(4 * x - reach, 0):4 * x + 4 + reach] = True
+    return dict(roots=roots, unexplained=unexplained, seed=seed, differing=int((zsym != ref).sum()), total=int(ref.size))
 
 
 def first_decoder_index_mismatch(g, pre, idx_taps, groups, slice_depth, h, w):

@@ -96,10 +96,10 @@ def test_reference_harness_call_sequence_through_dropin(tmp_path, oracle_w0):
             if v is not None:
                 sys.modules[k] = v
 
-    # (the synthetic I-frame weight set is not fitted to reproduce its input: ~11 dB key frame, so the P-frames chained on it sit
-    #  near 13 dB -- the numbers only have to be sane here; parity is what the oracle comparison below checks)
-    assert rows[0][1] > 0 and np.isfinite(rows[0][2]) and rows[0][2] > 8
-    assert all(r[1] > 0 and np.isfinite(r[2]) and r[2] > 8 for r in rows[1:]), [r[:3] for r in rows]
+    # (round 4: the synthetic I-frame weight set decodes a usable key frame -- tools/calibrate_icip.py, ~27 dB at this size, border-limited --,
+    #  so the P-frames chained on it are pictures too; parity is what the oracle comparison below checks)
+    assert rows[0][1] > 0 and np.isfinite(rows[0][2]) and rows[0][2] > 22, rows[0][:3]
+    assert all(r[1] > 0 and np.isfinite(r[2]) and r[2] > 15 for r in rows[1:]), [r[:3] for r in rows]
 
     # ---- the same P-frames on the CPU oracle (same weights, same decoded key frame, same padded frames): identical bytes,
     #      decoded frame / feature within the fp32 parity bounds ----

@@ -254,15 +254,18 @@ def test_1080p_f16_against_reference(g1080):
 
 
 def test_1080p_intra_key_frame_against_reference(g1080):
-    """ICIP2020ResB (image_model.py:490-591) at 1088x1920 against the reference's run (byte-identical at 64 / 128 px:
-    tests/test_gpu_icip.py).  The un-fitted synthetic I-frame weights make sigma a small difference of large terms (relative
-    GPU-vs-CPU discrepancy up to ~3e-4 instead of ~1e-6), so at 2.6 M decisions a fraction of a percent of the symbols flips: the
-    checks here are rate (<= 0.02 %), share of differing symbols, the decoded picture against the reference's, PSNR; f16 mode the same
-    at the f16 bounds."""
+    """ICIP2020ResB (image_model.py:490-591) at 1088x1920 against the reference's run, held to the P-FRAME standard since round 4: the synthetic
+    I-frame weights are now a well-conditioned (structured) set that decodes a usable key frame (tools/calibrate_icip.py: 30.96 dB in the
+    reference's own run).  fp32 mode: every differing HYPER-latent symbol must be a rounding the reference took within 2e-5 of flipping (a z
+    root: ~1 expected per frame at this size -- 98 k decisions behind K = 4800 sums), every differing y symbol / index must be such a decision
+    too or lie inside the receptive field downstream of a root (the fraction of the latent map that stays under the strict check is
+    printed), bytes within 1e-4, identical strings when there is no root at all, block means of the decoded picture within 2e-3, PSNR
+    within 0.005 dB; f16 mode: 1 % bytes, 0.05 dB, the f16 bound on the picture."""
     from deepsvc_amd import ops, synth
     g, x = g1080, synth.make_frames(1088, 1920, 1)[0].to(DEV)
     want = {"strings": [[g["icip1080/enc/y"].tobytes()], [g["icip1080/enc/z"].tobytes()]], "shape": tuple(int(v) for v in g["icip1080/enc/shape"])}
-    psnr_ref = None
+    ref_psnr = float(g["icip1080/psnr"][0])
+    assert ref_psnr > 25.0, f"the reference's own key frame decodes at {ref_psnr:.2f} dB: not a usable picture"
     try:
         for mode in ("fp32", "f16"):
             ops.set_precision(mode)
@@ -273,19 +276,32 @@ def test_1080p_intra_key_frame_against_reference(g1080):
             dec = m.decompress(enc["strings"], enc["shape"])["x_hat"]
             b_g, b_r = _nbytes(enc), _nbytes(want)
             e_s, e_b, _ = PU.golden_full_errors(g, "icip1080/dec/x_hat", dec)
-            line = f"[parity] icip 1080p {mode}: {b_g} B vs reference {b_r} B ({100.0 * (b_g - b_r) / b_r:+.4f} %), x_hat samples rel-L2 {e_s:.2e}, block means {e_b:.2e}"
+            p_g = PU.psnr(dec.cpu(), x.cpu())
+            line = (f"[parity] icip 1080p {mode}: {b_g} B vs reference {b_r} B ({100.0 * (b_g - b_r) / b_r:+.4f} %), PSNR {p_g:.4f} vs {ref_psnr:.4f} dB, "
+                    f"x_hat samples rel-L2 {e_s:.2e}, block means {e_b:.2e}")
             if mode == "fp32":
-                _, ysym, yidx = PU.product_symbol_planes(m, 68, 120, DEV)
-                r = PU.explain_plane_mismatches(g, "icip1080/enc/y", ysym, yidx, m.slice_depth, m.max_support_slices, idx_tol=3e-4, sym_tol=3e-4)
-                print(line + f"; differing symbols {r['symbols']} / indexes {r['indexes']} of {r['total']}, roots {len(r['roots'])}, not traced to a listed fragile decision {len(r['unexplained'])}")
-                # (the hyper-latent z = h_a(y) is rounded too, and with these weights some of its 98 k decisions flip as well:
-                #  the z string has the reference's length, not its bytes)
-                assert len(enc["strings"][1][0]) == len(want["strings"][1][0])
-                assert abs(b_g - b_r) <= 2e-4 * b_r and r["symbols"] <= 0.01 * r["total"]
-                assert e_s <= 2e-2 and e_b <= 2e-3
+                zsym, ysym, yidx = PU.product_symbol_planes(m, 68, 120, DEV)
+                # hyper-latent first: 98 k rounding decisions behind three convs of K = 2880 .. 4800 terms -- about one of them per frame falls
+                # within the ~3e-6 by which two fp32 summation orders differ; such a z root moves mu / sigma of the latent pixels around it
+                rz = PU.explain_hyper_mismatches(g, "icip1080/enc/", zsym, (68, 120))
+                r = PU.explain_plane_mismatches(g, "icip1080/enc/y", ysym, yidx, m.slice_depth, m.max_support_slices, seed=rz["seed"] if rz["seed"].any() else None)
+                print(line + f"; z symbols differing {rz['differing']} of {rz['total']} (roots {[(k, f'{mg:.1e}') for k, mg in rz['roots']]}, unexplained {len(rz['unexplained'])}); "
+                      f"y: differing symbols {r['symbols']} / indexes {r['indexes']} of {r['total']}, roots {[(k, kind, f'{mg:.1e}') for k, kind, mg in r['roots']]}, "
+                      f"unexplained {len(r['unexplained'])}; share of the latent map outside every earlier root's reach, slice by slice: {[round(v, 2) for v in r['strictly_checked']]}")
+                assert not rz["unexplained"], f"hyper-latent symbols differ where the reference's rounding was not fragile: {rz['unexplained'][:5]}"
+                assert not r["unexplained"], f"differences that no fragile decision of the reference explains: {r['unexplained'][:5]}"
+                # observed on MI355X: 1 z root (margin 2.4e-6), 18 y roots (margins 0 .. 2e-5) of 2.6 M decisions -- the I-frame codec's parameter
+                # stacks sum K = 2880 .. 4320 terms (320-channel latent + supports), three times the P-frame codecs', hence more roots per decision
+                assert len(rz["roots"]) <= 4 and len(r["roots"]) <= 40 and abs(b_g - b_r) <= 1e-4 * b_r, (len(rz["roots"]), len(r["roots"]))
+                if not rz["roots"]:
+                    assert enc["strings"][1] == want["strings"][1], "no z root, yet the hyper-latent string differs from the reference's"
+                if not rz["roots"] and not r["roots"]:
+                    assert enc["strings"][0] == want["strings"][0] and e_s <= 1e-5 and e_b <= 1e-5
+                # a flipped symbol moves ONE decimated sample of the picture by 1/16: the picture agrees except there
+                assert e_b <= 2e-3 and abs(p_g - ref_psnr) <= 0.005, (e_s, e_b, p_g)
             else:
                 print(line)
-                assert abs(b_g - b_r) <= 0.01 * b_r and e_s <= 2e-2 and e_b <= 4e-3
+                assert abs(b_g - b_r) <= 0.01 * b_r and abs(p_g - ref_psnr) <= 0.05 and e_s <= PU.F16_BOUNDS["recon"] and e_b <= PU.F16_BOUNDS["recon"]
     finally:
         ops.set_precision("fp32")
 

@@ -49,9 +49,9 @@ class Calib:
         add_t = torch.as_tensor(add, dtype=torch.float32)
         self.sd[key] = self.sd[key] * mul + add_t
         cur = self.spec.get(key, {"mul": 1.0, "add": 0.0})
-        prev = torch.as_tensor(cur["add"], dtype=torch.float32)
+        prev = torch.as_tensor(cur.get("add", 0.0), dtype=torch.float32)
         new_add = prev * mul + add_t
-        self.spec[key] = {"mul": cur["mul"] * mul, "add": new_add.tolist() if new_add.dim() else float(new_add)}
+        self.spec[key] = dict(cur, mul=cur.get("mul", 1.0) * mul, add=new_add.tolist() if new_add.dim() else float(new_add))
 
     def set(self, key, value):
         self.sd[key] = value.to(torch.float32).clone()
