@@ -338,7 +338,7 @@ def main():
         alg_bytes = (2.0 + nres[0]) * H_pad * W_pad * 64 * esz       # input + output + the residual operand(s), launch-weighted mean
         r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[precision],
              "traffic": None,
-             "kernel": f"3x3 s1 64->64 conv @{H_pad}x{W_pad}, all epilogue variants ({'conv3x3_pp_kernel' if precision == 'f16' else 'conv_mfma_kernel'})",
+             "kernel": f"3x3 s1 64->64 conv @{H_pad}x{W_pad}, all epilogue variants ({'conv3x3_pp_kernel' if precision == 'f16' else 'conv3x3_pps_kernel<float> (two residual operands: conv_mfma_kernel)'})",
              "launches": len(durs), "avg_ms": avg_ms, "min_ms": min(durs),
              "algorithmic_flop": conv_flop, "algorithmic_bytes": alg_bytes, "mean_residual_operands": nres[0],
              "hbm_view": {"achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK / 1e9, "frac": alg_bytes / (avg_ms * 1e-3) / HBM_PEAK,

@@ -31,6 +31,9 @@ def short(n):
     m = re.match(r"_ZN12_GLOBAL__N_116conv_mfma_kernelI(DF16_|f)Li(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)EEEvN9dsvc", n)
     if m:
         n = f"conv_mfma_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'}, MT={m.group(2)}, NT={m.group(3)}, FAST={m.group(4)}, REGEPI={m.group(5)}, PF={m.group(6)}>"
+    m = re.match(r"_ZN12_GLOBAL__N_118conv3x3_pps_kernelI(DF16_|f)Lb(\d)EEEvN9dsvc", n)
+    if m:
+        n = f"conv3x3_pps_kernel<{'f16' if m.group(1) == 'DF16_' else 'float'}, ACT={m.group(2)}>"
     return n
 
 
@@ -167,7 +170,9 @@ if all(os.path.exists(p) for p in (pf, pw, ps)):
         entries = []
         for key in F32c:
             name, wgs = key
-            if not (name.startswith("conv_mfma_kernel<f32, MT=2, NT=2") or name.startswith("conv_mfma_kernel<float, 2, 2,")) or wgs != 8160 or key not in W32c:
+            general = (name.startswith("conv_mfma_kernel<f32, MT=2, NT=2") or name.startswith("conv_mfma_kernel<float, 2, 2,")) and wgs == 8160
+            streamed = name.startswith("conv3x3_pps_kernel<float") and wgs == 256         # round 4: the 64 -> 64 family's two-group kernel (persistent grid)
+            if not (general or streamed) or key not in W32c:
                 continue
             fv, wv = F32c[key]["FETCH_SIZE"], W32c[key]["WRITE_SIZE"]
             if len(fv) != len(wv):
@@ -185,8 +190,8 @@ if all(os.path.exists(p) for p in (pf, pw, ps)):
                                 "algorithmic_bytes_per_launch": (2 + k) * tensor})
         if entries:
             n = sum(e["launches"] for e in entries)
-            full["fp32"] = {"kernel": "conv_mfma_kernel<f32, MT=2, NT=2, FAST=1>: 3x3 s1 64->64 launches @1088x1920 of one P-frame, fp32 storage "
-                                      "(launches reading 2 tensors include the few two-segment 64+64->64 convs of the same grid)",
+            full["fp32"] = {"kernel": "conv3x3_pps_kernel<float> (0 / 1 residual operands) + conv_mfma_kernel<f32, MT=2, NT=2, FAST=1> (2 residual operands): 3x3 s1 64->64 "
+                                      "launches @1088x1920 of one P-frame, fp32 storage (launches reading 2 tensors include the few two-segment 64+64->64 convs)",
                             "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (one pass each) -- python3 bench.py --precision fp32 --lanes 1 --steps 2 --warmup 2 --no-side-legs --no-cpu-baseline",
                             "launches": n,
                             "hbm_bytes_per_launch_corrected": sum(e["hbm_bytes_per_launch_corrected"] * e["launches"] for e in entries) / n,
