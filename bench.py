@@ -267,18 +267,25 @@ def main():
             L["stream"].synchronize()
 
     def warm(lanes, n):
-        """One lane at a time: weight packing and HIP-graph capture need a quiescent device (no other thread launching).
-        With several lanes a lane's graphs are only final once EVERY lane has packed its weights, so lanes whose graphs are
-        not in place after n steps get the few extra untimed steps they need."""
-        for _ in range(max(n, 1) + (1 if intra else 0)):
+        """One lane at a time, each to completion: DeepSVC.warm_up codes chained P-frames of the lane's GOP until that instance's scan graphs
+        and frame programs (both variants) are in place -- everything a recording depends on belongs to the instance, so there is nothing to
+        retry across lanes.  `n` (--warmup) further untimed steps per lane follow, one lane at a time."""
+        for L in lanes:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(L["stream"]):
+                if intra:
+                    key = pad(L["frames"][0], 64)
+                    enc = L["imodel"].compress(key)
+                    ref = L["imodel"].decompress(enc["strings"], enc["shape"])["x_hat"]
+                else:
+                    ref = pad(L["frames"][0], 64)
+                took = L["model"].warm_up(ref, [pad(f, 64) for f in L["frames"][1:]], L["sm"][1:])
+                L["stream"].synchronize()
+            L["warm_frames"] = took
+        for _ in range(max(n, 0)):
             for L in lanes:
                 run_lane(L, 1, False)
-        for _ in range(4):
-            todo = [L for L in lanes if not L["model"].graphs_ready(1, H_pad, W_pad, dev)]
-            if not todo:
-                break
-            for L in todo:
-                run_lane(L, 1, False)
+        assert all(L["model"].graphs_ready(1, H_pad, W_pad, dev) for L in lanes)
         for L in lanes:                      # every timed region starts at a GOP boundary
             L["t"] = 0
 

@@ -122,36 +122,24 @@ def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None, overla
     (sequential by bitstream format); other lanes' kernels fill those gaps.  Results are identical to
     coding the GOPs one after the other with code_gop (every kernel is deterministic); rows come back ordered by GOP.
 
-    Weight packing and HIP-graph capture need a quiescent device, so each lane is first warmed up alone on the first
-    P-frame of its first GOP (result discarded) until its graphs are in place."""
+    Weight packing and HIP-graph capture need a quiescent device, so each lane is first warmed up alone on the P-frames of its
+    first GOP (results discarded) with DeepSVC.warm_up, which returns when that instance's graphs and frame programs are in place."""
     import threading
     L = len(models)
     assert L >= 1 and (i_models is None or len(i_models) == L)
     streams = [torch.cuda.Stream(device) for _ in range(L)]
     mine = [[u for u in range(len(gops)) if u % L == ln] for ln in range(L)]
 
-    def warm(ln):
+    for ln in range(L):                      # one lane at a time, each to completion (DeepSVC.warm_up: deterministic, no cross-lane retries)
         if not mine[ln]:
-            return
+            continue
         frames, sms = gops[mine[ln][0]]
         with torch.cuda.stream(streams[ln]):
-            ref, feat = pad(frames[0], 64), None
+            ref = pad(frames[0], 64)
             if i_models is not None:
                 enc = i_models[ln].compress(ref)
                 ref = i_models[ln].decompress(enc["strings"], enc["shape"])["x_hat"]
-            for t in range(1, min(len(frames), 3)):       # first AND steady-state P-frame: some layers are first used with `feature`
-                cur = pad(frames[t], 64)
-                mv, res = models[ln].compress(ref, cur, sms[t], feat)
-                feat, ref, _, _ = models[ln].decompress(ref, mv, res, sms[t], feat)
-            streams[ln].synchronize()
-
-    for _ in range(4):                       # a lane's graphs are final only once every lane has packed its weights
-        todo = [ln for ln in range(L) if mine[ln] and not models[ln].graphs_ready(
-            1, -(-gops[mine[ln][0]][0][0].shape[-2] // 64) * 64, -(-gops[mine[ln][0]][0][0].shape[-1] // 64) * 64, device)]
-        if not todo:
-            break
-        for ln in todo:
-            warm(ln)
+            models[ln].warm_up(ref, [pad(f, 64) for f in frames[1:]], list(sms[1:]))
     out, errors = {}, []
 
     def lane(ln):

@@ -86,6 +86,28 @@ class DeepSVC(nn.Module):
             codec.capture_scan_graphs(ref.B, ref.H // 16, ref.W // 16, ref.device)
         self.__dict__["_seen_epoch"] = epochs()
 
+    @torch.no_grad()
+    def warm_up(self, ref_frame, frames, sm_feas, max_frames=8):
+        """Deterministic warm-up of THIS model instance on the calling thread's current stream (the caller makes sure no other thread
+        is issuing HIP work: weight packing and graph capture want a quiescent device): codes chained P-frames -- frames[0] with
+        feature = None (first-frame variant), the following ones in steady state, cycling through `frames` / `sm_feas` -- until every scan
+        segment of both codecs has its HIP graph and the frame segments of both variants have been replayed once.  Everything a
+        recording depends on belongs to this instance (per-codec packing epoch, per-model program cache), so other instances (GOP lanes)
+        warming up before or after do not invalidate it.  -> number of frames coded; raises if the model is not ready after max_frames."""
+        ref, feat = ref_frame, None
+        first = ops.to_act(ref_frame)
+        B, H, W = first.B, first.H, first.W
+        n = 0
+        while n < max_frames:
+            cur, sm = frames[n % len(frames)], sm_feas[n % len(sm_feas)]
+            mv, res = self.compress(ref, cur, sm, feat)
+            feat, ref, _, _ = self.decompress(ref, mv, res, sm, feat)
+            n += 1
+            if n >= 3 and self.graphs_ready(B, H, W, first.device):        # frame 1: first variant recorded; 2: steady recorded; 3: both replayed, graphs in place
+                torch.cuda.current_stream(first.device).synchronize()
+                return n
+        raise RuntimeError(f"DeepSVC.warm_up: scan graphs not in place after {max_frames} frames (is another thread issuing HIP work / repacking weights?)")
+
     @staticmethod
     def _bpp(liks, pixels):
         total = sum(ops.reduce("sumlog", l) for l in liks)
