@@ -7,8 +7,11 @@
 // integer CDF tables of the four entropy models.  Loading allocates all of that on the device and resolves the relocations; coding a frame
 // is then: patch the three caller-owned frame tensors into the op arrays, issue the segments with dsvc_pframe_segment_run, and run the
 // host range coder between them exactly where the bitstream format puts it (image_model.py:206-207,221,253-254 / :260,273-274,288).
-// Single stream, strictly sequential (the Python layer additionally overlaps the residual decode chain on a side stream).
+// Overlap, as in the Python layer: the motion strings are range-coded on a worker thread while the GPU runs prediction and the residual
+// analysis; the residual decode chain (host range decoder <-> scan kernels, one synchronisation per level) runs on a worker thread and a side
+// stream owned by the program, beside the motion chain and the prediction segment of the caller's stream.
 #include <cstring>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
@@ -70,8 +73,12 @@ struct dsvc_pframe_program {
     void* owned[SLOT_N] = {nullptr};         // library-owned frame tensors: ref / cur (NHWC fp32), recon / warped / predict (NHWC fp32)
     Program seg[2][6];                       // [variant][E1, E2a, E2, D1, DR, D2]
     Codec codec[2];
+    hipStream_t side = nullptr;              // the residual decode chain's stream
+    hipEvent_t ev_stage = nullptr, ev_side = nullptr, ev_main = nullptr;
     ~dsvc_pframe_program() {
         (void)hipSetDevice(device);
+        if (side) (void)hipStreamDestroy(side);
+        for (hipEvent_t e : {ev_stage, ev_side, ev_main}) if (e) (void)hipEventDestroy(e);
         for (void* p : tensors) if (p) (void)hipFree(p);
         for (void* p : arena) if (p) (void)hipFree(p);
         for (void* p : owned) if (p) (void)hipFree(p);
@@ -148,10 +155,15 @@ int run_program(Program& pr, void* stream, void* const* caller) {
     return dsvc_pframe_segment_run(stream, pr.ops.data(), (int32_t)pr.ops.size());
 }
 
-// host half of one codec's encoder (image_model.py:206-207,221,237-254): symbols / indexes leave the device in one copy, z and y are range-coded
-int encode_codec(Codec& c, hipStream_t st, uint8_t* out_y, int64_t cap_y, int64_t* n_y, uint8_t* out_z, int64_t cap_z, int64_t* n_z) {
+// host half of one codec's encoder (image_model.py:206-207,221,237-254): symbols / indexes leave the device in one copy (stage_out, stream-ordered),
+// then z and y are range-coded on the host (encode_host: after the copy's event)
+int stage_out(Codec& c, hipStream_t st, hipEvent_t ev) {
     HIP_OK(hipMemcpyAsync(c.h_stage, c.staging, (size_t)(c.nz + 2 * c.ny) * 4, hipMemcpyDeviceToHost, st), "pframe_compress: copy of the symbol planes");
-    HIP_OK(hipStreamSynchronize(st), "pframe_compress: synchronize");
+    HIP_OK(hipEventRecord(ev, st), "pframe_compress: hipEventRecord");
+    return DSVC_OK;
+}
+int encode_host(Codec& c, hipEvent_t ev, uint8_t* out_y, int64_t cap_y, int64_t* n_y, uint8_t* out_z, int64_t cap_z, int64_t* n_z) {
+    HIP_OK(hipEventSynchronize(ev), "pframe_compress: synchronize");
     void* enc = nullptr;
     if (int rc = dsvc_rans_encoder_create(&enc)) return rc;
     struct Guard { void* e; ~Guard() { dsvc_rans_encoder_destroy(e); } } guard{enc};
@@ -165,6 +177,8 @@ int encode_codec(Codec& c, hipStream_t st, uint8_t* out_y, int64_t cap_y, int64_
     *n_y = n;
     return DSVC_OK;
 }
+// a worker thread's result: the error text is thread-local, so it travels with the code
+struct Outcome { int rc; std::string msg; };
 
 // one codec's decode chain (image_model.py:259-297): z string -> z_hat -> level by level: index planes to the host, range decoder, symbols back
 int decode_codec(Codec& c, hipStream_t st, const uint8_t* y, int64_t ny_bytes, const uint8_t* z, int64_t nz_bytes, void* const* caller) {
@@ -273,6 +287,8 @@ extern "C" int dsvc_pframe_program_load(const void* blob, int64_t nbytes, int32_
         for (int s = 0; s < 6; ++s) DSVC_REQUIRE(P->seg[v][s].present, "pframe_program_load: segment %s (variant %d) missing from the blob", kSegNames[s], v);
     for (int ci = 0; ci < 2; ++ci)
         for (auto& d : P->codec[ci].dec) DSVC_REQUIRE(d.present, "pframe_program_load: a decoder level of codec %d is missing from the blob", ci);
+    HIP_OK(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking), "pframe_program_load: hipStreamCreate");
+    for (hipEvent_t* e : {&P->ev_stage, &P->ev_side, &P->ev_main}) HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming), "pframe_program_load: hipEventCreate");
     HIP_OK(hipDeviceSynchronize(), "pframe_program_load: synchronize");
     *out = P.release();
     return DSVC_OK;
@@ -304,10 +320,21 @@ extern "C" int dsvc_pframe_compress(dsvc_pframe_program* P, void* stream, const 
     if (int rc = dsvc_nchw_to_nhwc(stream, ref, P->owned[SLOT_REF], 3, DSVC_F32, 1, 3, P->H, P->W)) return rc;
     if (int rc = dsvc_nchw_to_nhwc(stream, cur, P->owned[SLOT_CUR], 3, DSVC_F32, 1, 3, P->H, P->W)) return rc;
     if (int rc = run_program(P->seg[v][0], stream, caller)) return rc;                                              // E1
-    if (int rc = encode_codec(P->codec[0], st, out[0], cap[0], &nbytes[0], out[1], cap[1], &nbytes[1])) return rc;  // motion strings
-    if (int rc = run_program(P->seg[v][1], stream, caller)) return rc;                                              // E2a
-    if (int rc = run_program(P->seg[v][2], stream, caller)) return rc;                                              // E2
-    return encode_codec(P->codec[1], st, out[2], cap[2], &nbytes[2], out[3], cap[3], &nbytes[3]);                   // residual strings
+    if (int rc = stage_out(P->codec[0], st, P->ev_stage)) return rc;
+    // the motion strings are coded on a worker thread while the GPU runs prediction + the residual analysis (E2a, E2)
+    const int dev = P->device;
+    auto mv_job = std::async(std::launch::async, [P, dev, out, cap, nbytes]() {
+        (void)hipSetDevice(dev);
+        const int rc = encode_host(P->codec[0], P->ev_stage, out[0], cap[0], &nbytes[0], out[1], cap[1], &nbytes[1]);
+        return Outcome{rc, rc ? std::string(dsvc_last_error()) : std::string()};
+    });
+    int rc = run_program(P->seg[v][1], stream, caller);                                                             // E2a
+    if (!rc) rc = run_program(P->seg[v][2], stream, caller);                                                        // E2
+    if (!rc) rc = stage_out(P->codec[1], st, P->ev_main);
+    if (!rc) rc = encode_host(P->codec[1], P->ev_main, out[2], cap[2], &nbytes[2], out[3], cap[3], &nbytes[3]);      // residual strings
+    const Outcome mv = mv_job.get();
+    if (mv.rc) { dsvc_set_error("%s", mv.msg.c_str()); return mv.rc; }
+    return rc;
 }
 
 extern "C" int dsvc_pframe_decompress(dsvc_pframe_program* P, void* stream, const float* ref, const uint8_t* const strings[4], const int64_t nbytes[4],
@@ -320,11 +347,28 @@ extern "C" int dsvc_pframe_decompress(dsvc_pframe_program* P, void* stream, cons
     void* caller[SLOT_N] = {nullptr};
     caller[SLOT_SM_FEA] = (void*)sm_fea; caller[SLOT_FEATURE_IN] = (void*)feature; caller[SLOT_FEATURE_OUT] = feature_out;
     if (int rc = dsvc_nchw_to_nhwc(stream, ref, P->owned[SLOT_REF], 3, DSVC_F32, 1, 3, P->H, P->W)) return rc;
-    if (int rc = decode_codec(P->codec[0], st, strings[0], nbytes[0], strings[1], nbytes[1], caller)) return rc;    // motion chain
-    if (int rc = run_program(P->seg[v][3], stream, caller)) return rc;                                              // D1
-    if (int rc = decode_codec(P->codec[1], st, strings[2], nbytes[2], strings[3], nbytes[3], caller)) return rc;    // residual chain
-    if (int rc = run_program(P->seg[v][4], stream, caller)) return rc;                                              // DR
-    if (int rc = run_program(P->seg[v][5], stream, caller)) return rc;                                              // D2
+    // The residual chain depends on its strings and its own scan workspace only: worker thread + the program's side stream, beside the motion
+    // chain and the prediction segment of the caller's stream; the side stream first waits for what the caller had queued (the encoder of this
+    // frame may still be reading the shared scan workspace when compress() and decompress() are called back to back).
+    HIP_OK(hipEventRecord(P->ev_main, st), "pframe_decompress: hipEventRecord");
+    HIP_OK(hipStreamWaitEvent(P->side, P->ev_main, 0), "pframe_decompress: hipStreamWaitEvent");
+    const int dev = P->device, var = v;
+    void* caller_copy[SLOT_N];
+    std::memcpy(caller_copy, caller, sizeof(caller));
+    auto res_job = std::async(std::launch::async, [P, dev, var, strings, nbytes, &caller_copy]() {
+        (void)hipSetDevice(dev);
+        int rc = decode_codec(P->codec[1], P->side, strings[2], nbytes[2], strings[3], nbytes[3], caller_copy);   // residual chain
+        if (!rc) rc = run_program(P->seg[var][4], (void*)P->side, caller_copy);                                   // DR
+        if (!rc && hipEventRecord(P->ev_side, P->side) != hipSuccess) { dsvc_set_error("pframe_decompress: hipEventRecord (side)"); rc = DSVC_E_LAUNCH; }
+        return Outcome{rc, rc ? std::string(dsvc_last_error()) : std::string()};
+    });
+    int rc = decode_codec(P->codec[0], st, strings[0], nbytes[0], strings[1], nbytes[1], caller);                   // motion chain
+    if (!rc) rc = run_program(P->seg[v][3], stream, caller);                                                        // D1
+    const Outcome res = res_job.get();
+    if (res.rc) { dsvc_set_error("%s", res.msg.c_str()); return res.rc; }
+    if (rc) return rc;
+    HIP_OK(hipStreamWaitEvent(st, P->ev_side, 0), "pframe_decompress: hipStreamWaitEvent");
+    if ((rc = run_program(P->seg[v][5], stream, caller))) return rc;                                                // D2
     // decoded frames back in the reference's layout (video_model.py:167 returns NCHW tensors)
     struct { int slot; float* dst; } outs[3] = {{SLOT_RECON, recon}, {SLOT_WARPED, warped}, {SLOT_PREDICT, predict}};
     for (auto& o : outs)
