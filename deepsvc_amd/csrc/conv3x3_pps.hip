@@ -42,6 +42,23 @@ __device__ __forceinline__ void ps_store16(rsrc_t r, unsigned off, uint4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
 }
 __device__ __forceinline__ float ps_lrelu(float x, float slope) { return __builtin_amdgcn_fmed3f(x, x * slope, __builtin_inff()); }
+// 8 packed f16 -> max(x, x * slope) -> 8 packed f16, bit-identical to cvt -> fmaxf(x, x * slope) -> cvt (see conv3x3_pp.hip: act_h16x8)
+__device__ __forceinline__ uint4 ps_act_h16x8(uint4 val, float slope) {
+    unsigned u[4] = {val.x, val.y, val.z, val.w};
+    if (slope == 0.f) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm("v_pk_max_i16 %0, %1, 0" : "=v"(u[k]) : "v"(u[k]));
+        return make_uint4(u[0], u[1], u[2], u[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned t = 0;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "+v"(t) : "v"(u[k]), "v"(slope));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(u[k]), "v"(slope));
+        asm("v_pk_max_f16 %0, %1, %2" : "=v"(u[k]) : "v"(u[k]), "v"(t));
+    }
+    return make_uint4(u[0], u[1], u[2], u[3]);
+}
 
 // CT = h16: f16 storage and MFMA (v_mfma_f32_32x32x16_f16), activation none / ReLU / LeakyReLU (ACT), no residuals (the shapes above).
 // CT = float [round 4]: fp32 storage and v_mfma_f32_32x32x2_f32 -- the PARITY mode's arithmetic -- over 16-channel chunks (64 bytes, so
@@ -51,8 +68,10 @@ __device__ __forceinline__ float ps_lrelu(float x, float slope) { return __built
 // loaded where they are used.  Operation order per output element is the general kernel's (conv_mfma.hip + epilogue_vec): MFMAs by
 // (chunk, tap, 16-byte half, element), + bias, activation, + (res1 + res2) -- fp32 results are bit-identical to it, which is what keeps
 // the byte-identity tests against the reference green.
-template <typename CT, bool ACT>
-__global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p, int ntiles, int iters, float act_slope) {
+// EXT (f16 only) [r4]: output-channel split (96 / 128 output channels as two passes of 64), pre-activation on the staged patch, one f16 residual.
+// Kept out of the plain instantiations at compile time: they sit at 238-244 VGPRs and the extra address arithmetic spilled them.
+template <typename CT, bool ACT, bool EXT = false>
+__global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p, int ntiles, int iters, float act_slope, int nsplit_arg) {
     DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MTW = 2, NT = 2;
@@ -67,7 +86,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
     float* lds_bias = (float*)(smem + 2 * PS_WBYTES + 2 * PS_NPATCH * ROWB);               // 64 floats
     const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
     const int NCH = p.nchunks;
-    const rsrc_t rw = make_rsrc(p.w, (unsigned)NCH * PS_WROWS * 64u);
+    // OUTPUT-CHANNEL SPLIT [r4]: a conv with 96 / 128 output channels runs as nsplit = 2 passes of 64 channels inside ONE launch -- workgroup b
+    // computes channels [64 (b % nsplit), +64) (the weight buffers are shared by the two groups of a workgroup, so a workgroup owns one pass) and
+    // walks the tiles among the gridDim / nsplit workgroups of its pass; the input patch is staged once per pass (L2 / MALL hits at 1/2 - 1/4
+    // resolution).  96 channels: the second pass computes 32 real + 32 zero-weight columns (the packed weights are padded to Np rows, rows beyond
+    // that are masked) and stores the real ones.
+    static_assert(!(EXT && sizeof(CT) == 4), "the extended variant is f16 only");
+    const int nsplit = EXT ? nsplit_arg : 1;
+    const int csel = EXT ? (int)blockIdx.x % nsplit : 0, wgi = EXT ? (int)blockIdx.x / nsplit : (int)blockIdx.x, nwg = EXT ? (int)gridDim.x / nsplit : (int)gridDim.x;
+    const int n0 = EXT ? csel * PS_NTN : 0;
+    const rsrc_t rw = make_rsrc(p.w, (unsigned)NCH * 9u * (unsigned)p.Np * 64u);
 
     const int H = p.H, W = p.W, tiles_x = p.tiles_x, tiles_y = p.tiles_y;
     struct TileOrg { int b, oy0, ox0; };
@@ -110,6 +138,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
             const int pix = (gtid >> 2) + 64 * j;
             if (pix >= PS_NPATCH) continue;
             uint4 v = pf[j];
+            if constexpr (EXT) {
+                if (p.pre_act != DSVC_ACT_NONE) v = ps_act_h16x8(v, pre_sl);     // ResBlock1's leading ReLU / LeakyReLU on the packed patch (as conv3x3_pp.hip)
+            }
             if constexpr (F32) {
                 if (p.pre_act != DSVC_ACT_NONE) {        // ResBlock1's leading activation, exactly as the general kernel applies it while staging
                     unsigned u[4] = {v.x, v.y, v.z, v.w};
@@ -125,12 +156,26 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
         }
     };
     // ---- weight staging: half `g` of a chunk = rows [288 g, 288 g + 288), vector v = gtid + 256 j -> row v >> 2, quarter v & 3 ----
+    // (LDS row r = tap * 64 + n of this pass <-> packed row (chunk * 9 + tap) * Np + n0 + n; rows beyond Np read zeros)
     auto load_whalf = [&](int ch, uint4 (&wv)[PS_WV]) {
-        const unsigned base = ((unsigned)ch * PS_WROWS + (unsigned)g * PS_HALF) * 64u + q * 16u;
+        if constexpr (!EXT) {
+            const unsigned base = ((unsigned)ch * PS_WROWS + (unsigned)g * PS_HALF) * 64u + q * 16u;
 #pragma unroll
-        for (int j = 0; j < PS_WV; ++j) {
-            const unsigned row = (unsigned)(gtid >> 2) + 64u * j;
-            wv[j] = buf_load16(rw, (base + row * 64u) | (row < (unsigned)PS_HALF ? 0u : OOB));
+            for (int j = 0; j < PS_WV; ++j) {
+                const unsigned row = (unsigned)(gtid >> 2) + 64u * j;
+                wv[j] = buf_load16(rw, (base + row * 64u) | (row < (unsigned)PS_HALF ? 0u : OOB));
+            }
+        } else {
+            // row r_j = 288 g + (gtid >> 2) + 64 j: 64 more rows are exactly one more tap of the same channel, i.e. + Np rows in the packed layout
+            const unsigned r0 = (unsigned)g * PS_HALF + (unsigned)(gtid >> 2);
+            const unsigned nn = (unsigned)n0 + (r0 & 63u), tstep = (unsigned)p.Np * 64u;
+            const unsigned base = (((unsigned)ch * 9u + (r0 >> 6)) * (unsigned)p.Np + nn) * 64u + q * 16u;
+            const unsigned nok = nn < (unsigned)p.Np ? 0u : OOB;
+#pragma unroll
+            for (int j = 0; j < PS_WV; ++j) {
+                const unsigned row = (unsigned)(gtid >> 2) + 64u * j;
+                wv[j] = buf_load16(rw, (base + (unsigned)j * tstep) | nok | (row < (unsigned)PS_HALF ? 0u : OOB));
+            }
         }
     };
     auto store_whalf = [&](int buf, uint4 (&wv)[PS_WV]) {
@@ -159,25 +204,28 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
 #pragma unroll
             for (int m = 0; m < MTW; ++m) af[m] = *(const uint4*)(lds_a + a_off[m] + tap_off + ks * 16);
         };
-        uint4 af[3][MTW], bf[3][NT];
+        // fragments are read FST - 1 k-steps ahead: two for f16 (one step = 4 MFMAs = 128 cycles does not cover the ds_read latency beside the other
+        // group's LDS traffic), one for fp32 (a step is 16 MFMAs = 1024 cycles; the third register set would spill)
+        constexpr int FST = 3;
+        uint4 af[FST][MTW], bf[FST][NT];
         read_frags(0, af[0], bf[0]);
-        read_frags(1, af[1], bf[1]);
+        if constexpr (FST == 3) read_frags(1, af[1], bf[1]);
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s2 = 0; s2 < 18; ++s2) {
-            if (s2 + 2 < 18) read_frags(s2 + 2, af[(s2 + 2) % 3], bf[(s2 + 2) % 3]);
+            if (s2 + FST - 1 < 18) read_frags(s2 + FST - 1, af[(s2 + FST - 1) % FST], bf[(s2 + FST - 1) % FST]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     if constexpr (F32) {
-                        const f32x4 a4 = __builtin_bit_cast(f32x4, af[s2 % 3][m]), b4 = __builtin_bit_cast(f32x4, bf[s2 % 3][n]);
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, af[s2 % FST][m]), b4 = __builtin_bit_cast(f32x4, bf[s2 % FST][n]);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j], a4[j], acc[m][n], 0, 0, 0);   // D[channel][pixel]
                     } else {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, bf[s2 % 3][n]),   // D[channel][pixel]
-                                                                             __builtin_bit_cast(h16x8, af[s2 % 3][m]), acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, bf[s2 % FST][n]),   // D[channel][pixel]
+                                                                             __builtin_bit_cast(h16x8, af[s2 % FST][m]), acc[m][n], 0, 0, 0);
                     }
                 }
             asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));   // pin the accumulation order (conv3x3_pp.hip)
@@ -195,12 +243,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
     };
     // epilogue lane roles: see conv3x3_pp.hip (row_off / PP_TILE): after the two swap levels lane l of vector `half` holds pixel
     // (l & 15) + 16 half of the tile row and channels 16 ((l >> 4) & 1) + 8 (l >> 5) .. +7 of the N-tile
-    auto row_off = [&](const TileOrg& t, int m, bool valid, int half) -> unsigned {
+    auto row_off = [&](const TileOrg& t, int m, bool valid, int half, int ld) -> unsigned {
         const int oy = t.oy0 + wg * MTW + m;
         const int px = (r & 15) + 16 * half;
         const unsigned pix = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0) + px;
-        return (__umul24(pix & 0xFFFFFFu, (unsigned)p.out_ld * 2) + 32 * (r >> 4) + 16 * h) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
+        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + 2 * n0 + 32 * (r >> 4) + 16 * h) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
     };
+    const rsrc_t rres = EXT ? make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? p.res1_bytes : p.out_bytes) : rout;
+    const bool has_r1 = EXT && p.res1 != nullptr;
+    const unsigned nmask[NT] = {(!EXT || n0 < p.Cout) ? 0u : OOB, (!EXT || n0 + 32 < p.Cout) ? 0u : OOB};       // an N-tile of zero-weight padding columns is not stored
 #define PS_SWAP32(X, Y, LO, HI)                                                                                     \
     { const float xq = (X), yq = (Y);   /* scalars first: hipcc 7.2 mis-casts vector elements */                    \
       const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false); \
@@ -282,17 +333,28 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
         if constexpr (ACT) {                                                                                        \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) { v0[j] = ps_lrelu(v0[j], act_slope); v1[j] = ps_lrelu(v1[j], act_slope); } \
         }                                                                                                           \
+        if constexpr (EXT) if (has_r1) {      /* the residual arrives in the MEMORY layout; the (involutive) 16-lane swap brings it to the compute layout (conv3x3_pp.hip) */ \
+            const uint4 ra = rres_v[(M * NT + N) * 2], rb = rres_v[(M * NT + N) * 2 + 1];                           \
+            const unsigned ma[4] = {ra.x, ra.y, ra.z, ra.w}, mb[4] = {rb.x, rb.y, rb.z, rb.w};                      \
+            unsigned xa[4], xb[4];                                                                                  \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) PS_SWAP16(ma[d], mb[d], xa[d], xb[d])                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+                v0[2 * j] += h16_lo(xa[j]); v0[2 * j + 1] += h16_hi(xa[j]);                                         \
+                v1[2 * j] += h16_lo(xb[j]); v1[2 * j + 1] += h16_hi(xb[j]);                                         \
+            }                                                                                                       \
+        }                                                                                                           \
         unsigned s0[4], s1[4];                                                                                      \
         _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                               \
             PS_SWAP16(pk_h16(v0[2 * d], v0[2 * d + 1]), pk_h16(v1[2 * d], v1[2 * d + 1]), s0[d], s1[d])             \
-        ps_store16(rout, o_out[M][0] + 64 * N, make_uint4(s0[0], s0[1], s0[2], s0[3]));                             \
-        ps_store16(rout, o_out[M][1] + 64 * N, make_uint4(s1[0], s1[1], s1[2], s1[3]));                             \
+        ps_store16(rout, (o_out[M][0] + 64 * N) | nmask[N], make_uint4(s0[0], s0[1], s0[2], s0[3]));                \
+        ps_store16(rout, (o_out[M][1] + 64 * N) | nmask[N], make_uint4(s1[0], s1[1], s1[2], s1[3]));                \
     }
 
     // ---- XCD-aware tile walk (conv3x3_pp.hip) ----
-    const int nband = (gridDim.x % 8 == 0) ? 8 : 1, per = (int)gridDim.x / nband;
-    const int band = (int)blockIdx.x % nband, band_tiles = (ntiles + nband - 1) / nband;
-    const int lt0 = ((int)blockIdx.x / nband) * 2 + g;
+    // (with nsplit = 2 the workgroups of a band still share an XCD: blockIdx = 2 wgi + csel, and wgi = band (mod 8) fixes blockIdx mod 8)
+    const int nband = (nwg % 8 == 0) ? 8 : 1, per = nwg / nband;
+    const int band = wgi % nband, band_tiles = (ntiles + nband - 1) / nband;
+    const int lt0 = (wgi / nband) * 2 + g;
     auto tile_of = [&](int k) {            // tile index, or ntiles when this (group, k) has no tile
         const int lt = lt0 + k * 2 * per;
         const int t = band * band_tiles + lt;
@@ -316,10 +378,15 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
 #pragma unroll
         for (int j = 0; j < NWV; ++j) {
             const unsigned row = (unsigned)(tid >> 2) + 128u * j;
-            w0[j] = buf_load16(rw, (row * 64u + q4 * 16u) | (row < (unsigned)PS_WROWS ? 0u : OOB));
+            if constexpr (!EXT) w0[j] = buf_load16(rw, (row * 64u + q4 * 16u) | (row < (unsigned)PS_WROWS ? 0u : OOB));
+            else {      // rows (tid >> 2) + 128 j: two more taps per step
+                const unsigned r0 = (unsigned)(tid >> 2), nn = (unsigned)n0 + (r0 & 63u);
+                const unsigned off = ((r0 >> 6) + 2u * j) * (unsigned)p.Np * 64u + nn * 64u + q4 * 16u;
+                w0[j] = buf_load16(rw, off | ((row < (unsigned)PS_WROWS && nn < (unsigned)p.Np) ? 0u : OOB));
+            }
         }
         load_whalf(1 % NCH, wv);
-        if (tid < PS_NTN) lds_bias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
+        if (tid < PS_NTN) lds_bias[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;
         store_chunk(pfA);                                  // the patch loads were issued first and return first
 #pragma unroll
         for (int j = 0; j < NWV; ++j) {
@@ -356,10 +423,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
                 tile_f32(cur, acc[1][1], 1, 1, valid, RA);
             } else {
                 unsigned o_out[MTW][2];
+                uint4 rres_v[EXT ? MTW * NT * 2 : 1];
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) o_out[m][half] = row_off(cur, m, valid, half);
+                    for (int half = 0; half < 2; ++half) {
+                        o_out[m][half] = row_off(cur, m, valid, half, p.out_ld);
+                        if constexpr (EXT) {
+                            // one f16 residual (ResBlock1.conv2 of the 128-channel bottleneck blocks): all eight vectors requested before the first is used
+                            const unsigned rb = has_r1 ? row_off(cur, m, valid, half, p.res1_ld) : OOB;
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) rres_v[(m * NT + n) * 2 + half] = buf_load16(rres, (rb + 64 * n) | nmask[n]);
+                        }
+                    }
                 PS_TILE(0, 0) PS_TILE(0, 1) PS_TILE(1, 0) PS_TILE(1, 1)
             }
             c = 0; ++k;
@@ -385,21 +461,21 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
 #undef PS_SWAP32
 }
 
-template <typename CT, bool ACT>
-int launch_pps(hipStream_t st, const ConvParams& p, int ntiles, float act_slope) {
+template <typename CT, bool ACT, bool EXT = false>
+int launch_pps(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, int nsplit = 1) {
     const size_t lds = (size_t)2 * PS_WBYTES + (size_t)2 * PS_NPATCH * ROWB + (size_t)PS_NTN * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv3x3_pps_kernel<CT, ACT>;
+    auto kern = conv3x3_pps_kernel<CT, ACT, EXT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
         attr_set = true;
     }
-    int grid = (ntiles + 1) / 2;
-    if (grid > 256) grid = 256;                                   // one persistent workgroup per CU, two tiles in flight each
-    const int nband = grid % 8 == 0 ? 8 : 1, band_tiles = (ntiles + nband - 1) / nband;   // as in the kernel
-    const int iters = (band_tiles + 2 * (grid / nband) - 1) / (2 * (grid / nband));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, ntiles, iters, act_slope);
+    int nwg = (ntiles + 1) / 2;                                   // workgroups per output-channel pass
+    if (nwg > 256 / nsplit) nwg = 256 / nsplit;                   // one persistent workgroup per CU, two tiles in flight each
+    const int nband = nwg % 8 == 0 ? 8 : 1, band_tiles = (ntiles + nband - 1) / nband;   // as in the kernel
+    const int iters = (band_tiles + 2 * (nwg / nband) - 1) / (2 * (nwg / nband));
+    hipLaunchKernelGGL(kern, dim3(nwg * nsplit), dim3(512), lds, st, p, ntiles, iters, act_slope, nsplit);
     DSVC_CHECK_LAUNCH("conv3x3_pps_kernel");
     return DSVC_OK;
 }
@@ -411,8 +487,14 @@ bool ps_vec16_ok(const void* ptr, int ld, int esz) { return ((uintptr_t)ptr & 15
 // returns 1 when the shape is not covered (the caller falls through to the general kernel), else DSVC_OK / error
 int dsvc_conv3x3_pps_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->shuffle != 1) return 1;
-    if (p_in.nchunks < 3 || p_in.nchunks > 32 || d->Cout != 64 || d->res1_scale || d->post_weight) return 1;
+    if (p_in.nchunks > 32 || d->res1_scale || d->post_weight) return 1;
     const bool f32 = d->compute == DSVC_F32;
+    // 64 output channels: 3+ chunks (two chunks are conv3x3_pp.hip's, weights resident); f16 also 96 / 128 output channels as two passes of 64
+    // (measured, tools/bench_pps.py, us streamed / general: 128->128 @272x480 45 / 50; 96->96 @544x960 114 / 116 and @272x480 36 / 32 -- the second
+    //  pass computes 32 padding columns; 64->128 @272x480 29 / 30: only the first is on by default, pps = 2 forces the others for the tests)
+    const bool split_ok = !f32 && ((d->Cout == 128 && p_in.nchunks >= 4) || (g_dsvc_opt.pps >= 2 && (d->Cout == 96 || d->Cout == 128) && p_in.nchunks >= 2));
+    const int nsplit = d->Cout == 64 ? 1 : (split_ok ? 2 : 0);
+    if (nsplit == 0 || (nsplit == 1 && p_in.nchunks < 3)) return 1;
     const int esz = f32 ? 4 : 2, epv = f32 ? 4 : 8, dt = f32 ? DSVC_F32 : DSVC_F16;
     for (int s = 0; s < p_in.nseg; ++s) {                          // every pixel's chunk row is an aligned run of 16-byte vectors
         const ConvSeg& sg = p_in.seg[s];
@@ -428,16 +510,19 @@ int dsvc_conv3x3_pps_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv
         // two residual operands: 16 dependent-latency loads per tile pair in the epilogue -- measured slower than the general kernel
         // (1375 vs 1337 us, tools/bench_pps.py); forced by pps_f32 = 2 (tests)
         if (d->res1 && d->res2 && g_dsvc_opt.pps_f32 < 2) return 1;
-    } else if (d->res1 || d->res2 || d->pre_act != DSVC_ACT_NONE) {
-        return 1;
+    } else {                                                       // f16: pre-activation and ONE f16 residual are run-time parameters
+        if (d->res2) return 1;
+        if (d->res1 && (d->res1_dtype != DSVC_F16 || !ps_vec16_ok(d->res1, d->res1_ld, 2))) return 1;
     }
     ConvParams p = p_in;
     p.tiles_x = (p.Wo + 31) / 32;
     p.tiles_y = (p.Ho + PS_TH - 1) / PS_TH;
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;          // pixel indices go through the 24-bit multiplier
-    if (ntiles < 1024) return 1;                                   // small images: the general kernel's finer tiling fills the chip better
+    if (ntiles * nsplit < 1000) return 1;                          // small images: the general kernel's finer tiling fills the chip better
     if (f32) return launch_pps<float, false>(st, p, ntiles, 1.f);
     const float act_slope = d->act == DSVC_ACT_NONE ? 1.f : (d->act == DSVC_ACT_RELU ? 0.f : d->slope);
+    if (nsplit > 1 || d->res1 || d->pre_act != DSVC_ACT_NONE)          // output-channel split / pre-activation / residual: the extended instantiation
+        return d->act == DSVC_ACT_NONE ? launch_pps<h16, false, true>(st, p, ntiles, 1.f, nsplit) : launch_pps<h16, true, true>(st, p, ntiles, act_slope, nsplit);
     return d->act == DSVC_ACT_NONE ? launch_pps<h16, false>(st, p, ntiles, 1.f) : launch_pps<h16, true>(st, p, ntiles, act_slope);
 }

@@ -62,7 +62,8 @@ int dsvc_device_count(void);
  * whole pixel rows and transposes to the MFMA operand layout through LDS; 0: lanes address 32-byte pieces of 32 rows), "small_pf" (1: the
  * generic kernel's 4x32 / 8x32 x 32-channel variants prefetch the next channel chunk's input patch: small images, f16 storage), "pps" (1: f16 3x3
  * stride-1 convs over 3+ 32-channel input chunks with 64 output channels on >= 1024 tiles take the two-group kernel with weights streamed per
- * chunk, csrc/conv3x3_pps.hip; 0: the general kernel), "pps_f32" (1: ... and so do fp32 3x3 stride-1 convs with 64 output channels over 3+ 16-channel
+ * chunk, csrc/conv3x3_pps.hip -- also with a pre-activation or one f16 residual, and 128 -> 128 channels as two 64-column passes inside one
+ * launch; 2: also 96 / 128 output channels over 2+ chunks, measured no faster; 0: the general kernel), "pps_f32" (1: ... and so do fp32 3x3 stride-1 convs with 64 output channels over 3+ 16-channel
  * chunks -- the parity mode's 64 -> 64 family, any pre-activation / activation / fp32 residuals; bit-identical to the general kernel).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
  * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF, DSVC_NO_PPS, DSVC_NO_PPS_F32).

@@ -408,28 +408,37 @@ def test_conv_register_epilogue_matches_slab_epilogue(segs, cout, k, stride, B, 
     close_f16("register epilogue vs torch", reg, want)
 
 
-@pytest.mark.parametrize("segs,H,W,act", [
-    ((64, 64), 256, 1024, 0),        # fea_embd[0] (modules.py:401): four chunks, no activation, exactly 1024 tiles
-    ((64, 64), 250, 1000, 2),        # UNet.up_conv3's first conv (modules.py:262-277, LeakyReLU): ragged right / bottom tiles
-    ((64, 32), 256, 1024, 0),        # Reconstruction.first_conv (modules.py:322): three chunks (odd: the weight-buffer parity wraps)
-    ((64, 8), 264, 1056, 0),         # RefineNet.refine[0] (modules.py:307): an 8-channel packed segment = a chunk with one valid quarter
-    ((64, 64, 32), 256, 1024, 1),    # three segments, five chunks, ReLU
+@pytest.mark.parametrize("segs,cout,H,W,pre,act,res", [
+    ((64, 64), 64, 256, 1024, 0, 0, False),        # fea_embd[0] (modules.py:401): four chunks, no activation, exactly 1024 tiles
+    ((64, 64), 64, 250, 1000, 0, 2, False),        # UNet.up_conv3's first conv (modules.py:262-277, LeakyReLU): ragged right / bottom tiles
+    ((64, 32), 64, 256, 1024, 0, 0, False),        # Reconstruction.first_conv (modules.py:322): three chunks (odd: the weight-buffer parity wraps)
+    ((64, 8), 64, 264, 1056, 0, 0, False),         # RefineNet.refine[0] (modules.py:307): an 8-channel packed segment = a chunk with one valid quarter
+    ((64, 64, 32), 64, 256, 1024, 0, 1, False),    # three segments, five chunks, ReLU
+    # ---- output-channel split (two passes of 64 inside one launch), pre-activation, one residual: the extended instantiation ----
+    ((128,), 128, 272, 480, 1, 1, False),          # UNet.context_refine ResBlock1.conv1 (modules.py:373: ReLU before and after) @1/4 resolution: 2 x 510 tile jobs
+    ((128,), 128, 272, 480, 0, 0, True),           # ... conv2: + x
+    ((96,), 96, 256, 512, 0, 2, False),            # residual codec's ResBottleneck conv2 (image_model.py:22-38) @1/2: second pass = 32 real + 32 padding columns
+    ((64,), 128, 256, 1024, 0, 2, False),          # UNet.conv3's first conv 64 -> 128 (two chunks, two passes)
+    ((64, 64), 64, 256, 1024, 2, 2, True),         # pre-activation + activation + residual on a 64-channel output
 ])
-def test_streamed_weights_pp_kernel_matches_general_kernel(segs, H, W, act):
+def test_streamed_weights_pp_kernel_matches_general_kernel(segs, cout, H, W, pre, act, res):
     """csrc/conv3x3_pps.hip (two wave groups, weights streamed per 32-channel chunk through two LDS buffers) against the general kernel
-    on the same operands: the same MFMAs in the same order per output element, bias first -> EQUAL f16 results; and against torch on
-    f16-rounded operands at half an ulp.  The launch counter proves which kernel ran."""
+    on the same operands: the same MFMAs in the same order per output element, bias after the accumulation -> EQUAL f16 results; and
+    against torch on f16-rounded operands at half an ulp.  The launch counter proves which kernel ran."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
-    torch.manual_seed(sum(segs) + W + act)
+    torch.manual_seed(sum(segs) + W + act + cout + 5 * pre)
     bf = torch.float16
     ops.set_precision("f16")
-    was = ops.set_option("pps", 1)
+    was, was_pp = ops.set_option("pps", 2), ops.set_option("pp", 0)        # (pps 2: also the split shapes that are off by default; pp off: keeps two-chunk 64-output shapes away from the resident-weights kernel)
     try:
-        m = Conv2d(sum(segs), 64, 3, 1, 1).to(DEV)
+        m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
         xs = [torch.randn(1, c, H, W) for c in segs]
+        r = torch.randn(1, cout, H, W) if res else None
         ins = [_act(x, bf) for x in xs]
-        kw = dict(act=act, slope=0.05, out_dtype=bf)
+        kw = dict(pre_act=pre, act=act, slope=0.05, out_dtype=bf)
+        if res:
+            kw["res1"] = _act(r, bf)
         n0 = ops.get_counter("conv3x3_pps")
         got = m.run(ins, **kw).nchw().float().cpu()
         again = m.run(ins, **kw).nchw().float().cpu()
@@ -438,13 +447,15 @@ def test_streamed_weights_pp_kernel_matches_general_kernel(segs, H, W, act):
         ref = m.run(ins, **kw).nchw().float().cpu()
         assert ops.get_counter("conv3x3_pps") == n0 + 2
     finally:
-        ops.set_option("pps", was)
+        ops.set_option("pps", was); ops.set_option("pp", was_pp)
         ops.set_precision("fp32")
     assert torch.equal(got, again), "not deterministic"
     assert torch.equal(got, ref), f"streamed-weights and general kernel differ: max |d| = {float((got - ref).abs().max()):.3e} at {int((got != ref).sum())} elements"
     w, b = m.weight.detach().cpu().to(bf).float(), m.bias.detach().cpu()
-    xb = torch.cat([x.to(bf).float() for x in xs], 1)
+    xb = torch.cat([_torch_act(x.to(bf).float(), pre, 0.05).to(bf).float() for x in xs], 1)
     want = _torch_act(F.conv2d(xb, w, b, padding=1), act, 0.05)
+    if res:
+        want = want + r.to(bf).float()
     close_f16("streamed-weights kernel vs torch", got, want)
 
 

@@ -7,13 +7,14 @@ from deepsvc_amd.modules import Conv2d
 
 dev = "cuda:0"
 ops.set_precision("f16")
-SHAPES = [((64, 64), 1088, 1920, 0), ((64, 64), 544, 960, 2), ((64, 32), 1088, 1920, 0), ((64, 8), 1088, 1920, 0)]
-for segs, H, W, act in SHAPES:
+SHAPES = [((64, 64), 64, 1088, 1920, 0), ((64, 64), 64, 544, 960, 2), ((64, 32), 64, 1088, 1920, 0), ((64, 8), 64, 1088, 1920, 0),
+          ((128,), 128, 272, 480, 1), ((96,), 96, 544, 960, 2), ((96,), 96, 272, 480, 2), ((64,), 128, 272, 480, 2)]
+for segs, cout, H, W, act in SHAPES:
     torch.manual_seed(0)
-    m = Conv2d(sum(segs), 64, 3, 1, 1).to(dev)
+    m = Conv2d(sum(segs), cout, 3, 1, 1).to(dev)
     ins = [ops.Act(torch.randn((1, H, W, c), device=dev).to(torch.float16)) for c in segs]
-    out = ops.new_act(1, H, W, 64, torch.float16, dev)
-    flop = 2.0 * H * W * 64 * sum(segs) * 9
+    out = ops.new_act(1, H, W, cout, torch.float16, dev)
+    flop = 2.0 * H * W * cout * sum(segs) * 9
     res = {}
     for rnd in range(3):
         for opt in (1, 0):
@@ -29,7 +30,7 @@ for segs, H, W, act in SHAPES:
             res.setdefault(opt, []).append(e0.elapsed_time(e1) / 20 * 1e3)
     ops.set_option("pps", 1)
     a, b = min(res[1]), min(res[0])
-    print(f"3x3 {'+'.join(map(str, segs))} -> 64 @{H}x{W} act {act}: streamed-weights {a:7.1f} us ({flop / a / 1e6:6.0f} TFLOP/s = {flop / a / 1e6 / 2500:.3f} of peak)   "
+    print(f"3x3 {'+'.join(map(str, segs))} -> {cout} @{H}x{W} act {act}: streamed-weights {a:7.1f} us ({flop / a / 1e6:6.0f} TFLOP/s = {flop / a / 1e6 / 2500:.3f} of peak)   "
           f"general {b:7.1f} us ({flop / b / 1e6 / 2500:.3f})   rounds {['%.0f/%.0f' % (x, y) for x, y in zip(res[1], res[0])]}", flush=True)
 
 # ---- fp32 (parity) mode: the dominant 3x3 64 -> 64 shape and its epilogue variants ----
