@@ -26,6 +26,7 @@
 
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv1x1_f32_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv_head_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pps_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
@@ -827,6 +828,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     }
     if (opt.specialised && opt.conv1x1) {   // f16 pointwise convs: streaming kernel, no LDS staging
         const int rc = dsvc_conv1x1_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_CONV1X1);
+        if (rc != 1) return rc;
+    }
+    if (opt.specialised && opt.conv1x1_f32) {   // fp32 pointwise convs over 64 / 96 / 128 channels of whole images: streaming kernel, bit-identical to the general one
+        const int rc = dsvc_conv1x1_f32_try((hipStream_t)stream, p, d);
         if (rc == DSVC_OK) dsvc_count(DSVC_CNT_CONV1X1);
         if (rc != 1) return rc;
     }

@@ -505,6 +505,49 @@ def test_streamed_weights_pp_kernel_fp32_is_bit_identical_to_the_general_kernel(
     report_close("fp32 streamed-weights kernel vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W,act,res", [
+    (64, 64, 1, 137, 241, 0, True),       # ResBottleneckBlock.conv3 + x (modules.py:176-189), ragged last unit (33 017 pixels)
+    (64, 64, 1, 136, 240, 2, False),      # ... conv1 + LeakyReLU, whole units
+    (96, 96, 1, 272, 480, 0, True),       # the residual codec's bottlenecks (image_model.py:22-38) at 1/4 resolution
+    (96, 96, 2, 136, 240, 2, False),      # batch 2: one flat pixel list
+    (128, 128, 1, 136, 250, 1, True),     # widest: 82 KB of weights + 66 KB of tiles in LDS
+    (64, 128, 1, 136, 250, 1, False),
+    (128, 64, 1, 136, 250, 0, False),
+    (64, 96, 1, 136, 250, 2, True),
+])
+def test_fp32_pointwise_kernel_matches_general_kernel(cin, cout, B, H, W, act, res):
+    """csrc/conv1x1_f32.hip (fp32 mode's streaming 1x1 kernel: whole-row loads / stores, operand roles swapped) against the general
+    kernel: EQUAL bits -- same v_mfma_f32_32x32x2_f32 channel pairs in the same order, bias / activation / residual in the general
+    epilogue's order -- so fp32 mode's byte parity with the reference cannot move; and against torch fp32.  The counter proves which ran."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(cin + 3 * cout + W + act)
+    f32 = torch.float32
+    ops.set_precision("fp32")
+    was = ops.set_option("conv1x1_f32", 1)
+    try:
+        m = Conv2d(cin, cout, 1, 1, 0).to(DEV)
+        x = torch.randn(B, cin, H, W)
+        r = torch.randn(B, cout, H, W) if res else None
+        kw = dict(act=act, slope=0.01, out_dtype=f32)
+        if res:
+            kw["res1"] = _act(r, f32)
+        n0 = ops.get_counter("conv1x1")
+        got = m.run([_act(x, f32)], **kw).nchw().float().cpu()
+        assert ops.get_counter("conv1x1") == n0 + 1, "the fp32 streaming kernel did not take this shape"
+        ops.set_option("conv1x1_f32", 0)
+        ref = m.run([_act(x, f32)], **kw).nchw().float().cpu()
+        assert ops.get_counter("conv1x1") == n0 + 1
+    finally:
+        ops.set_option("conv1x1_f32", was)
+    assert torch.equal(got, ref), f"fp32 1x1: streaming and general kernel differ: max |d| = {float((got - ref).abs().max()):.3e} at {int((got != ref).sum())} elements"
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), "fp32 1x1: results differ in the sign of a zero"
+    want = _torch_act(F.conv2d(x, m.weight.detach().cpu(), m.bias.detach().cpu()), act, 0.01)
+    if res:
+        want = want + r
+    report_close("fp32 streaming 1x1 kernel vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("segs,cout,k,stride,H,W,act,res", [
     ((128,), 128, 3, 1, 160, 320, 1, True),        # UNet bottleneck ResBlock shape class: four N-tiles per workgroup
     ((96,), 128, 5, 2, 512, 512, 0, False),        # stride 2 (even/odd column LDS layout) with four N-tiles

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepsvc_amd import ops, synth, _native as N  # noqa: E402
 from deepsvc_amd.modules import pad  # noqa: E402
 
-ops.set_precision("f16")
+ops.set_precision(os.environ.get("CENSUS_MODE", "f16"))
 dev = "cuda:0"
 model = synth.make_model("W0"); model.update(force=True); model = model.to(dev)
 frames = [pad(f.to(dev), 64) for f in synth.make_frames(1080, 1920, 3)]
