@@ -644,6 +644,10 @@ int launch_ct(hipStream_t st, const ConvParams& p, int MT, int NT, bool fast, in
     }
     if constexpr (sizeof(CT) == 4) {
         if (fast && MT == 2 && NT == 2 && p.patchpf) return launch_cfg<CT, 2, 2, true, false, 6>(st, p, ngroups, lds);     // fp32: slab epilogue + patch prefetch
+        if (fast && MT == 1 && NT <= 3 && p.patchpf)         // small images: 4x32 tiles + patch prefetch, as in f16 mode
+            return NT == 1 ? launch_cfg<CT, 1, 1, true, false, 4>(st, p, ngroups, lds)
+                 : NT == 2 ? launch_cfg<CT, 1, 2, true, false, 4>(st, p, ngroups, lds) : launch_cfg<CT, 1, 3, true, false, 4>(st, p, ngroups, lds);
+        if (fast && MT == 2 && NT == 1 && p.patchpf) return launch_cfg<CT, 2, 1, true, false, 6>(st, p, ngroups, lds);
     }
     if (fast) return MT == 2 ? launch_nt<CT, 2, true>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, true>(st, p, NT, ngroups, lds);
     return MT == 2 ? launch_nt<CT, 2, false>(st, p, NT, ngroups, lds) : launch_nt<CT, 1, false>(st, p, NT, ngroups, lds);
@@ -910,7 +914,8 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         // small f16 launches (a few dozen to a few hundred workgroups, each a serial chain of stage -> MFMA per 32-channel chunk: the
         // entropy scan and the 1/8 - 1/16 resolution layers, ~250 launches per 1080p frame): the next chunk's patch loads ride under
         // the current chunk's weight commit and MFMAs (tools/phase_probe_tiny.py: patch staging was 25-30 % of a workgroup's clocks)
-        if (opt.patch_prefetch >= 1 && opt.small_pf && d->compute == DSVC_F16 && fast && same_type && p.nchunks >= 2 && !p.regepi &&
+        // (fp32 mode: the same variants over 16-channel chunks -- same bytes per pixel row, same register budget; staging only, bit-identical)
+        if (opt.patch_prefetch >= 1 && opt.small_pf && (d->compute == DSVC_F16 || opt.small_pf >= 1) && fast && same_type && p.nchunks >= 2 && !p.regepi && !p.patchpf &&
             ((MT == 1 && NT <= 3 && PH * PW <= 4 * 64) || (MT == 2 && NT == 1 && PH * PW <= 6 * 64)))
             p.patchpf = 1;
     }

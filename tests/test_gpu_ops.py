@@ -505,6 +505,43 @@ def test_streamed_weights_pp_kernel_fp32_is_bit_identical_to_the_general_kernel(
     report_close("fp32 streamed-weights kernel vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("segs,cout,H,W,pre,act,res", [
+    ((96,), 48, 68, 120, 0, 3, False),        # cc_mean / cc_scale second conv of the residual codec (image_model.py:114-146): GELU, 4x32 tiles x 2 N-tiles
+    ((96, 48), 96, 68, 120, 0, 3, False),     # ... first conv of slice 4: two segments, nine chunks, three N-tiles
+    ((64,), 32, 68, 120, 0, 3, False),        # one N-tile
+    ((64,), 64, 136, 240, 2, 2, True),        # 1/8-resolution ResBottleneck conv2 shape class with pre-activation and residual
+    ((48,), 12, 67, 119, 0, 5, True),         # lrp tail: 0.5 tanh, + residual, ragged tiles
+])
+def test_fp32_small_image_patch_prefetch_is_bit_identical(segs, cout, H, W, pre, act, res):
+    """fp32 mode's small launches (entropy-parameter nets, 1/8 - 1/16 resolution layers) take the general kernel's patch-prefetch variants
+    ("small_pf": the next 16-channel chunk's halo patch rides under the current chunk's MFMAs): staging only -- EQUAL bits with the option off."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + W)
+    f32 = torch.float32
+    ops.set_precision("fp32")
+    was = ops.set_option("small_pf", 1)
+    try:
+        m = Conv2d(sum(segs), cout, 3, 1, 1).to(DEV)
+        xs = [torch.randn(1, c, H, W) for c in segs]
+        r = torch.randn(1, cout, H, W) if res else None
+        kw = dict(pre_act=pre, act=act, slope=0.01, out_dtype=f32)
+        if res:
+            kw["res1"] = _act(r, f32)
+        ins = [_act(x, f32) for x in xs]
+        got = m.run(ins, **kw).nchw().float().cpu()
+        ops.set_option("small_pf", 0)
+        ref = m.run(ins, **kw).nchw().float().cpu()
+    finally:
+        ops.set_option("small_pf", was)
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), f"fp32 small_pf on / off differ at {int((got != ref).sum())} elements"
+    xb = torch.cat([_torch_act(x, pre, 0.01) for x in xs], 1)
+    want = _torch_act(F.conv2d(xb, m.weight.detach().cpu(), m.bias.detach().cpu(), padding=1), act, 0.01)
+    if res:
+        want = want + r
+    report_close("fp32 small-image conv vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,B,H,W,act,res", [
     (64, 64, 1, 137, 241, 0, True),       # ResBottleneckBlock.conv3 + x (modules.py:176-189), ragged last unit (33 017 pixels)
     (64, 64, 1, 136, 240, 2, False),      # ... conv1 + LeakyReLU, whole units
