@@ -26,6 +26,7 @@
 
 int dsvc_conv3x3_ws_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv1x1_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv_head_f32_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv1x1_f32_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv_head_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
@@ -827,6 +828,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     }
     if (opt.specialised && opt.head) {      // narrow f16 output heads (Cout <= 4) of large images: dot products on the vector ALU
         const int rc = dsvc_conv_head_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_HEAD);
+        if (rc != 1) return rc;
+    }
+    if (opt.specialised && opt.head_f32) {  // ... and of fp32 images: the MFMA's own fma chain on the vector ALU, bit-identical
+        const int rc = dsvc_conv_head_f32_try((hipStream_t)stream, p, d);
         if (rc == DSVC_OK) dsvc_count(DSVC_CNT_HEAD);
         if (rc != 1) return rc;
     }
