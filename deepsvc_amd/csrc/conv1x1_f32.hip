@@ -25,8 +25,9 @@ using namespace dsvc_conv;
 
 namespace {
 
-// KC: 16-channel input chunks; NT: 32-channel output tiles
-template <int KC, int NT, bool HAS_R1>
+// KC: 16-channel input chunks (of up to two segments: the virtual torch.cat of the up-path shortcuts); NT: 32-channel output tiles;
+// HAS_GATE: out = act(conv) + gate[c] * res1 (the SE gate of modules.py:226-247, batch 1)
+template <int KC, int NT, bool HAS_R1, bool HAS_GATE>
 __global__ void __launch_bounds__(256) conv1x1_f32_kernel(const ConvParams p, int nunits, int act, float slope) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPI = KC * 4, PPO = NT * 8;                        // 16-byte pieces per input / output pixel row
@@ -37,15 +38,22 @@ __global__ void __launch_bounds__(256) conv1x1_f32_kernel(const ConvParams p, in
     const int r = lane & 31, h = lane >> 5;
     char* lds_w = smem;                                              // [chunk][Np rows] at the 80-byte pitch
     float* lds_bias = (float*)(smem + (size_t)KC * p.Np * ROWB);
-    char* tile = smem + (size_t)KC * p.Np * ROWB + (size_t)p.Np * sizeof(float) + (size_t)wave * (32 * TP);
+    char* tile = smem + (size_t)KC * p.Np * ROWB + (size_t)2 * p.Np * sizeof(float) + (size_t)wave * (32 * TP);
     {
         const int nrows = KC * p.Np, q = tid & 3;
         for (int row = tid >> 2; row < nrows; row += 64)
             *(uint4*)(lds_w + row * ROWB + q * 16) = *(const uint4*)((const char*)p.w + (size_t)row * 64 + q * 16);
-        for (int c = tid; c < p.Np; c += 256) lds_bias[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        for (int c = tid; c < p.Np; c += 256) {
+            lds_bias[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+            if constexpr (HAS_GATE) lds_bias[p.Np + c] = c < p.Cout ? p.res1_scale[c] : 0.f;
+        }
     }
     __syncthreads();
     const rsrc_t rin = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
+    const bool two = p.nseg > 1;
+    const rsrc_t rin1 = make_rsrc(p.seg[two ? 1 : 0].ptr, p.seg[two ? 1 : 0].bytes);
+    const int pp0 = two ? p.seg[0].C / 4 : PPI;                      // pieces of a row served by segment 0
+    const unsigned pitch1 = (unsigned)p.seg[two ? 1 : 0].ld * 4;
     const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
     const rsrc_t rr1 = make_rsrc(HAS_R1 ? p.res1 : p.out, HAS_R1 ? p.res1_bytes : p.out_bytes);
     const unsigned pitch = (unsigned)p.seg[0].ld * 4, opitch = (unsigned)p.out_ld * 4, rpitch = (unsigned)p.res1_ld * 4;
@@ -58,7 +66,9 @@ __global__ void __launch_bounds__(256) conv1x1_f32_kernel(const ConvParams p, in
         for (int i = 0; i < NLI; ++i) {
             const int v = i * 64 + lane, px = v / PPI, pc = v - px * PPI;
             const unsigned pix = (unsigned)u * 32 + px;
-            g[i] = buf_load16(rin, (pix * pitch + (unsigned)pc * 16u) | ((uok && pix < npix) ? 0u : OOB));
+            const unsigned m = (uok && pix < npix) ? 0u : OOB;
+            g[i] = pc < pp0 ? buf_load16(rin, (pix * pitch + (unsigned)pc * 16u) | m)
+                            : buf_load16(rin1, (pix * pitch1 + (unsigned)(pc - pp0) * 16u) | m);
         }
     };
     auto load_gr = [&](int u, uint4 (&g)[NLO]) {                     // residual rows in the layout of the output rows
@@ -128,8 +138,14 @@ __global__ void __launch_bounds__(256) conv1x1_f32_kernel(const ConvParams p, in
             if constexpr (HAS_R1) {
                 const uint4 rv = r_nxt[i];
                 const unsigned ru[4] = {rv.x, rv.y, rv.z, rv.w};
-                o.x += __builtin_bit_cast(float, ru[0]); o.y += __builtin_bit_cast(float, ru[1]);
-                o.z += __builtin_bit_cast(float, ru[2]); o.w += __builtin_bit_cast(float, ru[3]);
+                if constexpr (HAS_GATE) {        // the general epilogue's v += gate * r1 + r2 with r2 = +0: the product is rounded, then added
+                    const float4 gt = *(const float4*)(lds_bias + p.Np + pc * 4);
+                    o.x += __fadd_rn(__fmul_rn(gt.x, __builtin_bit_cast(float, ru[0])), 0.f); o.y += __fadd_rn(__fmul_rn(gt.y, __builtin_bit_cast(float, ru[1])), 0.f);
+                    o.z += __fadd_rn(__fmul_rn(gt.z, __builtin_bit_cast(float, ru[2])), 0.f); o.w += __fadd_rn(__fmul_rn(gt.w, __builtin_bit_cast(float, ru[3])), 0.f);
+                } else {
+                    o.x += __builtin_bit_cast(float, ru[0]); o.y += __builtin_bit_cast(float, ru[1]);
+                    o.z += __builtin_bit_cast(float, ru[2]); o.w += __builtin_bit_cast(float, ru[3]);
+                }
             }
             const unsigned opx = (unsigned)unit * 32 + px;
             v4u_t ov;
@@ -145,13 +161,13 @@ __global__ void __launch_bounds__(256) conv1x1_f32_kernel(const ConvParams p, in
 template <int KC, int NT>
 int launch_f32(hipStream_t st, const ConvParams& p, int nunits, int act, float slope) {
     constexpr int PPI = KC * 4, PPO = NT * 8, TP = ((PPI > PPO ? PPI : PPO) + 1) * 16;
-    const size_t lds = (size_t)KC * p.Np * ROWB + (size_t)p.Np * sizeof(float) + (size_t)4 * 32 * TP;
+    const size_t lds = (size_t)KC * p.Np * ROWB + (size_t)2 * p.Np * sizeof(float) + (size_t)4 * 32 * TP;
     const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : ((int)((160 * 1024) / lds) > 4 ? 4 : (int)((160 * 1024) / lds));
     int grid = (nunits + 3) / 4;
     if (grid > 256 * per_cu) grid = 256 * per_cu;
-#define C1F_LAUNCH(R1)                                                                                                            \
+#define C1F_LAUNCH(R1, GATE)                                                                                                      \
     do {                                                                                                                          \
-        auto kern = conv1x1_f32_kernel<KC, NT, R1>;                                                                               \
+        auto kern = conv1x1_f32_kernel<KC, NT, R1, GATE>;                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set && lds > 64 * 1024) {                                                                                       \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
@@ -160,8 +176,9 @@ int launch_f32(hipStream_t st, const ConvParams& p, int nunits, int act, float s
         }                                                                                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, nunits, act, slope);                                          \
     } while (0)
-    if (p.res1) C1F_LAUNCH(true);
-    else C1F_LAUNCH(false);
+    if (p.res1 && p.res1_scale) C1F_LAUNCH(true, true);
+    else if (p.res1) C1F_LAUNCH(true, false);
+    else C1F_LAUNCH(false, false);
 #undef C1F_LAUNCH
     DSVC_CHECK_LAUNCH("conv1x1_f32_kernel");
     return DSVC_OK;
@@ -170,6 +187,7 @@ int launch_f32(hipStream_t st, const ConvParams& p, int nunits, int act, float s
 template <int KC>
 int launch_f32_nt(hipStream_t st, const ConvParams& p, int nunits, int NT, int act, float slope) {
     switch (NT) {
+        case 1: return launch_f32<KC, 1>(st, p, nunits, act, slope);
         case 2: return launch_f32<KC, 2>(st, p, nunits, act, slope);
         case 3: return launch_f32<KC, 3>(st, p, nunits, act, slope);
         default: return launch_f32<KC, 4>(st, p, nunits, act, slope);
@@ -181,24 +199,30 @@ int launch_f32_nt(hipStream_t st, const ConvParams& p, int nunits, int NT, int a
 // returns 1 when the shape is not covered (caller falls back to the general kernel), else DSVC_OK / error
 int dsvc_conv1x1_f32_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_desc* d) {
     if (d->compute != DSVC_F32 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->shuffle != 1) return 1;
-    if (d->nseg != 1 || d->pre_act != DSVC_ACT_NONE || d->res1_scale || d->res2 || d->post_weight) return 1;
+    if (d->nseg > 2 || d->pre_act != DSVC_ACT_NONE || d->res2 || d->post_weight || (d->res1_scale && (d->B > 1 || !d->res1))) return 1;
     if (p_in.out_bs || p_in.w_bs || p_in.res1_bs) return 1;       // per-item weights / placement: the general kernel's
     if (d->act != DSVC_ACT_NONE && d->act != DSVC_ACT_RELU && d->act != DSVC_ACT_LRELU) return 1;
-    const ConvSeg& sg = p_in.seg[0];
     auto v16 = [](const void* ptr, int ld) { return ((uintptr_t)ptr & 15) == 0 && (ld % 4) == 0; };
-    if (sg.dtype != DSVC_F32 || !v16(sg.ptr, sg.ld) || (sg.C != 64 && sg.C != 96 && sg.C != 128)) return 1;
-    if (d->Cout != 64 && d->Cout != 96 && d->Cout != 128) return 1;
+    int ctot = 0, ldin = 0;
+    for (int s = 0; s < d->nseg; ++s) {                        // whole 16-channel chunks of aligned fp32 rows
+        const ConvSeg& g = p_in.seg[s];
+        if (g.dtype != DSVC_F32 || !v16(g.ptr, g.ld) || (g.C % 16) != 0) return 1;
+        ctot += g.C;
+        ldin = g.ld > ldin ? g.ld : ldin;
+    }
+    if (ctot != 64 && ctot != 96 && ctot != 128) return 1;
+    if (d->Cout != 32 && d->Cout != 64 && d->Cout != 96 && d->Cout != 128) return 1;
     if (d->out_dtype != DSVC_F32 || !v16(d->out, d->out_ld)) return 1;
     if (d->res1 && (d->res1_dtype != DSVC_F32 || !v16(d->res1, d->res1_ld))) return 1;
     const int64_t npix = (int64_t)d->B * d->H * d->W;
     if (npix < 16 * 1024) return 1;                            // small images (the entropy-parameter nets) stay on the general kernel
-    const int64_t ldmax = sg.ld > d->out_ld ? (sg.ld > d->res1_ld ? sg.ld : d->res1_ld) : (d->out_ld > d->res1_ld ? d->out_ld : d->res1_ld);
+    const int64_t ldmax = ldin > d->out_ld ? (ldin > d->res1_ld ? ldin : d->res1_ld) : (d->out_ld > d->res1_ld ? d->out_ld : d->res1_ld);
     if ((npix + 64) * ldmax * 4 >= ((int64_t)1 << 31)) return 1;  // byte offsets are 31-bit (the masked value has bit 31 set)
     ConvParams p = p_in;
     p.B = 1; p.Ho = 1; p.Wo = (int)npix;
     const int nunits = (int)((npix + 31) / 32);
     const int NT = d->Cout / 32;
-    switch (sg.C / 16) {
+    switch (ctot / 16) {
         case 4: return launch_f32_nt<4>(st, p, nunits, NT, d->act, d->slope);
         case 6: return launch_f32_nt<6>(st, p, nunits, NT, d->act, d->slope);
         default: return launch_f32_nt<8>(st, p, nunits, NT, d->act, d->slope);

@@ -597,6 +597,10 @@ def test_fp32_small_image_patch_prefetch_is_bit_identical(segs, cout, H, W, pre,
     (64, 128, 1, 136, 250, 1, False),
     (128, 64, 1, 136, 250, 0, False),
     (64, 96, 1, 136, 250, 2, True),
+    ((32, 32), 64, 1, 136, 250, 0, "gate"),   # ConvBlockResidual tails (modules.py:233-247): up_dim(cat[a, b]) + gate[c] * branch
+    ((64, 64), 64, 1, 137, 241, 0, "gate"),
+    (64, 32, 1, 136, 250, 0, "gate"),         # one output tile
+    ((64, 32), 64, 1, 136, 250, 2, True),     # two segments of different widths, no gate
 ])
 def test_fp32_pointwise_kernel_matches_general_kernel(cin, cout, B, H, W, act, res):
     """csrc/conv1x1_f32.hip (fp32 mode's streaming 1x1 kernel: whole-row loads / stores, operand roles swapped) against the general
@@ -604,22 +608,28 @@ def test_fp32_pointwise_kernel_matches_general_kernel(cin, cout, B, H, W, act, r
     epilogue's order -- so fp32 mode's byte parity with the reference cannot move; and against torch fp32.  The counter proves which ran."""
     from deepsvc_amd import ops
     from deepsvc_amd.modules import Conv2d
-    torch.manual_seed(cin + 3 * cout + W + act)
+    segs = cin if isinstance(cin, tuple) else (cin,)
+    torch.manual_seed(sum(segs) + 3 * cout + W + act)
     f32 = torch.float32
     ops.set_precision("fp32")
     was = ops.set_option("conv1x1_f32", 1)
     try:
-        m = Conv2d(cin, cout, 1, 1, 0).to(DEV)
-        x = torch.randn(B, cin, H, W)
+        m = Conv2d(sum(segs), cout, 1, 1, 0).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        x = torch.cat(xs, 1)
         r = torch.randn(B, cout, H, W) if res else None
+        gate = torch.rand(1, cout) if res == "gate" else None
         kw = dict(act=act, slope=0.01, out_dtype=f32)
         if res:
             kw["res1"] = _act(r, f32)
+        if gate is not None:
+            kw["gate"] = gate.to(DEV)
+        ins = [_act(t, f32) for t in xs]
         n0 = ops.get_counter("conv1x1")
-        got = m.run([_act(x, f32)], **kw).nchw().float().cpu()
+        got = m.run(ins, **kw).nchw().float().cpu()
         assert ops.get_counter("conv1x1") == n0 + 1, "the fp32 streaming kernel did not take this shape"
         ops.set_option("conv1x1_f32", 0)
-        ref = m.run([_act(x, f32)], **kw).nchw().float().cpu()
+        ref = m.run(ins, **kw).nchw().float().cpu()
         assert ops.get_counter("conv1x1") == n0 + 1
     finally:
         ops.set_option("conv1x1_f32", was)
@@ -627,7 +637,7 @@ def test_fp32_pointwise_kernel_matches_general_kernel(cin, cout, B, H, W, act, r
     assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), "fp32 1x1: results differ in the sign of a zero"
     want = _torch_act(F.conv2d(x, m.weight.detach().cpu(), m.bias.detach().cpu()), act, 0.01)
     if res:
-        want = want + r
+        want = want + (r if gate is None else gate[:, :, None, None] * r)
     report_close("fp32 streaming 1x1 kernel vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
 
 
