@@ -34,6 +34,7 @@ struct ConvParams {
     int s2d;                                       // 1: inputs are a space-to-depth view of a (2H x 2W) image (dsvc.h)
     const void* post_w; const float* post_bias;    // fused trailing 1x1 conv (dsvc.h: post_weight), conv3x3_pp only
     int b_inner;                                   // see ConvSeg::bs_lo (dense batch: INT_MAX)
+    int skipk;                                     // 1: element-staged fp32 launches skip the all-zero MFMAs of narrow segments (conv_mfma_kernel: SKIPK)
     int patchpf;                                   // 1: ... with the next chunk's input patch prefetched into registers
     int regepi;                                    // 1: conv_mfma_kernel's register epilogue variant
     unsigned w_bytes;                              // extent of one item's packed weights (buffer-resource bound)

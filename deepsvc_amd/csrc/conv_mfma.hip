@@ -214,6 +214,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
 #ifdef DSVC_PP_CLOCK
     const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    constexpr bool SKIPK = !FAST && sizeof(CT) == 4;     // see mfma_tap
+    int kreal = 8;
     for (int ch = 0; ch < p.nchunks; ++ch) {
         PROBE_STAMP(t_a)
         int s = 0;
@@ -221,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         if (p.nseg > 2 && ch >= p.seg[2].chunk0) s = 2;
         const ConvSeg& sg = p.seg[s];
         const int c0 = (ch - sg.chunk0) * KCE;
+        if constexpr (SKIPK) kreal = __builtin_amdgcn_readfirstlane((p.skipk && sg.C - c0 < 8) ? sg.C - c0 : 8);
 
         lds_barrier();  // all waves done with the previous chunk's LDS contents (LDS-only: global traffic stays in flight)
         PROBE_STAMP(t_b)
@@ -321,6 +324,44 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                 for (int j = 0; j < PB; ++j)
                     if (base + 64 * j < npatch) *(uint4*)(lds_a + lr[j] * ROWB + q * 16) = v[j];
             }
+        } else if (sizeof(CT) == 4 && sg.dtype == DSVC_F32 && p.skipk) {
+            // element-staged fp32 segments (frames, flows: C % 4 != 0): bounds-checked DWORD loads, masked by the offset and issued four
+            // pixels ahead of the first LDS store -- the per-element path below waits out one L2 round trip per pixel (3 -> 64 3x3 at
+            // 1088x1920: 271 -> see tools/bench_narrow_f32.py).  Same values, same LDS image.
+            constexpr int PBN = 4;
+            const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);
+            const unsigned img0 = (unsigned)b * (unsigned)p.H * (unsigned)p.W;
+            const int cq = c0 + q * 4;
+            int py = py0, px = px0;
+            for (int base = pix0; base < npatch; base += 64 * PBN) {
+                unsigned u[PBN][4];
+                int lr[PBN];
+#pragma unroll
+                for (int j = 0; j < PBN; ++j) {
+                    const int iy = iy0 + py, ix = ix0 + px;
+                    lr[j] = lds_row(py, px);
+                    const bool inb = base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    const unsigned e0 = ((img0 + (unsigned)iy * p.W + (unsigned)ix) * (unsigned)sg.ld + (unsigned)cq) * 4u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        u[j][e] = __builtin_amdgcn_raw_buffer_load_b32(rs, (inb && cq + e < sg.C) ? e0 + 4u * e : OOB, 0, 0);
+                    px += dpx; py += dpy;
+                    if (px >= PW) { px -= PW; ++py; }
+                }
+                if (p.pre_act != DSVC_ACT_NONE) {
+                    const float sl = p.pre_act == DSVC_ACT_RELU ? 0.f : p.slope;
+#pragma unroll
+                    for (int j = 0; j < PBN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float f = __builtin_bit_cast(float, u[j][e]);
+                            u[j][e] = __builtin_bit_cast(unsigned, fmaxf(f, f * sl));
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < PBN; ++j)
+                    if (base + 64 * j < npatch) *(uint4*)(lds_a + lr[j] * ROWB + q * 16) = make_uint4(u[j][0], u[j][1], u[j][2], u[j][3]);
+            }
         } else {
             int py = py0, px = px0;
             for (int pix = pix0; pix < npatch; pix += 64) {
@@ -411,6 +452,23 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                 if (rt + 1 < tcur) { ++rt; if (++kx == p.kw) { kx = 0; ++ky; } }
             };
             auto mfma_tap = [&](const Frags& f) {
+                if constexpr (SKIPK) {
+                    // element-staged fp32 launches carry 2- / 3-channel segments (frames, flows): MFMA 4 ks + j of a chunk multiplies channels
+                    // 4 ks + j and 8 + 4 ks + j -- all zeros from channel `kreal` on; an all-zero fma step leaves the accumulator as it is, so
+                    // skipping it keeps the bits (3 of 8 MFMAs per tap for a 3-channel segment)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (4 * ks + j < kreal) {
+#pragma unroll
+                                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NT; ++n)
+                                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, f.a[ks][m])[j], __builtin_bit_cast(f32x4, f.b[ks][n])[j], acc[m][n], 0, 0, 0);
+                            }
+                    return;
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -916,6 +974,7 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         // (96 output channels: 256 registers with spills, 142 vs 129 us; with the k-step fragment pipeline to free registers 137 vs
         //  121 us for the tap-level pipeline without patch prefetch -- not taken)
         const bool f32_pf = d->compute == DSVC_F32 && fast && d->kh == 3 && d->kw == 3 && d->stride == 1 && !p.s2d;
+        p.skipk = opt.skip_zero_k != 0;
         p.patchpf = (p.regepi || f32_pf) && opt.patch_prefetch && MT == 2 && NT == 2 && same_type && PH * PW <= 6 * 64;
         // small f16 launches (a few dozen to a few hundred workgroups, each a serial chain of stage -> MFMA per 32-channel chunk: the
         // entropy scan and the 1/8 - 1/16 resolution layers, ~250 launches per 1080p frame): the next chunk's patch loads ride under

@@ -66,9 +66,10 @@ int dsvc_device_count(void);
  * launch; 2: also 96 / 128 output channels over 2+ chunks, measured no faster; 0: the general kernel), "pps_f32" (1: ... and so do fp32 3x3 stride-1 convs with 64 output channels over 3+ 16-channel
  * chunks -- the parity mode's 64 -> 64 family, any pre-activation / activation / fp32 residuals; bit-identical to the general kernel), "conv1x1_f32"
  * (1: fp32 1x1 convs over 64 / 96 / 128 channels of images of 16 K+ pixels take the streaming kernel csrc/conv1x1_f32.hip; bit-identical to the general kernel), "head_f32" (1: fp32 3x3 / 7x7 stride-1 convs with <= 4 output channels over whole 16-channel chunks of
- * images of 256+ tiles run as the MFMA's own fma chain on the vector ALU, csrc/conv_head_f32.hip; bit-identical to the general kernel).  Defaults come from
+ * images of 256+ tiles run as the MFMA's own fma chain on the vector ALU, csrc/conv_head_f32.hip; bit-identical to the general kernel), "skip_zero_k" (1: fp32 launches with 2- / 3-channel segments skip the MFMAs
+ * whose k slots hold only padding; bit-identical).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
- * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF, DSVC_NO_PPS, DSVC_NO_PPS_F32, DSVC_NO_1X1_F32, DSVC_NO_HEAD_F32).
+ * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF, DSVC_NO_PPS, DSVC_NO_PPS_F32, DSVC_NO_1X1_F32, DSVC_NO_HEAD_F32, DSVC_NO_SKIP_ZERO_K).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);

@@ -505,6 +505,39 @@ def test_streamed_weights_pp_kernel_fp32_is_bit_identical_to_the_general_kernel(
     report_close("fp32 streamed-weights kernel vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("segs,cout,k,stride,H,W,act", [
+    ((3,), 64, 3, 1, 130, 250, 0),            # FeatureExtraction's first conv on a frame (modules.py:364)
+    ((2, 3), 64, 3, 1, 130, 250, 0),          # RefineNet(mv) first conv on cat[mv, ref] (modules.py:307)
+    ((3, 2, 3), 64, 5, 2, 128, 256, 0),       # mv codec g_a[0] on cat[cur, mv, ref] (image_model.py:53-66), stride 2
+    ((3, 3, 2), 32, 7, 1, 68, 130, 1),        # MEBasic's first conv on cat[im1, warped, flow] (modules.py:127)
+    ((64, 3), 64, 3, 1, 130, 250, 0),         # a full segment beside a narrow one: only the narrow chunk skips
+    ((5,), 64, 3, 1, 40, 70, 2),              # five channels: second k step partly valid
+])
+def test_fp32_zero_k_slots_skipped_bit_identically(segs, cout, k, stride, H, W, act):
+    """fp32 launches with 2- / 3-channel segments (frames, flows: element-staged, C % 4 != 0) skip the MFMAs whose two k slots hold only
+    channel padding ("skip_zero_k"): an fma step with zero operands leaves the accumulator as it is -> EQUAL bits with the option off."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + k)
+    f32 = torch.float32
+    ops.set_precision("fp32")
+    was = ops.set_option("skip_zero_k", 1)
+    try:
+        m = Conv2d(sum(segs), cout, k, stride, k // 2).to(DEV)
+        xs = [torch.randn(1, c, H, W) for c in segs]
+        ins = [_act(x, f32) for x in xs]
+        kw = dict(act=act, slope=0.01, out_dtype=f32)
+        got = m.run(ins, **kw).nchw().float().cpu()
+        ops.set_option("skip_zero_k", 0)
+        ref = m.run(ins, **kw).nchw().float().cpu()
+    finally:
+        ops.set_option("skip_zero_k", was)
+    nd = int((got.view(torch.int32) != ref.view(torch.int32)).sum())
+    assert nd == 0, f"skip_zero_k on / off differ at {nd} of {got.numel()} elements"
+    want = _torch_act(F.conv2d(torch.cat(xs, 1), m.weight.detach().cpu(), m.bias.detach().cpu(), stride=stride, padding=k // 2), act, 0.01)
+    report_close("fp32 narrow-segment conv vs torch", got, want, 1e-5, 3e-5 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("segs,cout,k,H,W,B,act,nres", [
     ((64,), 3, 3, 250, 1100, 1, 4, 0),        # Reconstruction's sigmoid mask head (modules.py:322-340): ragged tiles
     ((64,), 3, 3, 256, 1024, 1, 0, 0),        # ... its image heads
