@@ -70,7 +70,7 @@ __device__ __forceinline__ uint4 ps_act_h16x8(uint4 val, float slope) {
 // the byte-identity tests against the reference green.
 // EXT (f16 only) [r4]: output-channel split (96 / 128 output channels as two passes of 64), pre-activation on the staged patch, one f16 residual.
 // Kept out of the plain instantiations at compile time: they sit at 238-244 VGPRs and the extra address arithmetic spilled them.
-template <typename CT, bool ACT, bool EXT = false>
+template <typename CT, bool ACT, bool EXT = false, bool R1P = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p, int ntiles, int iters, float act_slope, int nsplit_arg) {
     DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -283,6 +283,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
             R.b[2 * P2] = buf_load16(rr2, e2); R.b[2 * P2 + 1] = buf_load16(rr2, e2 + 16u);
         }
     };
+    // R1P (fp32, ONE residual operand -- ResBlock1.conv2 + x, 22 launches per frame): half the operand registers per tile, so the NEXT 32x32
+    // tile's loads are in flight behind the current tile's arithmetic and stores (two sets, same register count as one two-operand set)
+    auto res1_issue = [&](const TileOrg& t, int m, int n, bool valid, uint4 (&ra)[4]) {
+        unsigned pm, opix, c0;
+        tile_pos(t, m, n, valid, &pm, &opix, &c0);
+#pragma unroll
+        for (int P2 = 0; P2 < 2; ++P2) {
+            const unsigned e1 = ((opix * (unsigned)p.res1_ld + c0 + 16u * P2) * 4u) | pm;
+            ra[2 * P2] = buf_load16(rr1, e1); ra[2 * P2 + 1] = buf_load16(rr1, e1 + 16u);
+        }
+    };
     auto tile_f32 = [&](const TileOrg& t, const f32x16& a, int m, int n, bool valid, const ResRegs& R) {
         float v0[8], v1[8];
 #pragma unroll
@@ -303,7 +314,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
                 const float x = v[j] + bq[j];
                 v[j] = p.act == DSVC_ACT_RELU ? (x > 0.f ? x : 0.f) : (p.act == DSVC_ACT_LRELU ? (x > 0.f ? x : x * p.slope) : x);
             }
-            if (has_res) {              // + (res1 + res2), the general kernel's order (conv_common.h: epilogue_vec); an absent operand reads zeros
+            if (R1P || has_res) {       // + (res1 + res2), the general kernel's order (conv_common.h: epilogue_vec); an absent operand reads zeros
                 const uint4 f1a = R.a[2 * P2], f1b = R.a[2 * P2 + 1], f2a = R.b[2 * P2], f2b = R.b[2 * P2 + 1];
                 const unsigned u1[8] = {f1a.x, f1a.y, f1a.z, f1a.w, f1b.x, f1b.y, f1b.z, f1b.w}, u2[8] = {f2a.x, f2a.y, f2a.z, f2a.w, f2b.x, f2b.y, f2b.z, f2b.w};
 #pragma unroll
@@ -413,6 +424,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
             const bool valid = tile_of(k) < ntiles;
             if constexpr (F32) {
                 ResRegs RA;              // (two sets -- the next tile's operands in flight behind the current one -- spilled: 256 VGPRs + 184 B of scratch)
+                if constexpr (R1P) {
+                    ResRegs RB;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) RA.b[i] = RB.b[i] = make_uint4(0u, 0u, 0u, 0u);      // the absent second operand reads zeros (constants, no registers)
+                    res1_issue(cur, 0, 0, valid, RA.a);
+                    res1_issue(cur, 0, 1, valid, RB.a);
+                    tile_f32(cur, acc[0][0], 0, 0, valid, RA);
+                    res1_issue(cur, 1, 0, valid, RA.a);
+                    tile_f32(cur, acc[0][1], 0, 1, valid, RB);
+                    res1_issue(cur, 1, 1, valid, RB.a);
+                    tile_f32(cur, acc[1][0], 1, 0, valid, RA);
+                    tile_f32(cur, acc[1][1], 1, 1, valid, RB);
+                } else {
                 if (has_res) res_issue(cur, 0, 0, valid, RA);
                 tile_f32(cur, acc[0][0], 0, 0, valid, RA);
                 if (has_res) res_issue(cur, 0, 1, valid, RA);
@@ -421,6 +445,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
                 tile_f32(cur, acc[1][0], 1, 0, valid, RA);
                 if (has_res) res_issue(cur, 1, 1, valid, RA);
                 tile_f32(cur, acc[1][1], 1, 1, valid, RA);
+                }
             } else {
                 unsigned o_out[MTW][2];
                 uint4 rres_v[EXT ? MTW * NT * 2 : 1];
@@ -461,11 +486,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
 #undef PS_SWAP32
 }
 
-template <typename CT, bool ACT, bool EXT = false>
+template <typename CT, bool ACT, bool EXT = false, bool R1P = false>
 int launch_pps(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, int nsplit = 1) {
     const size_t lds = (size_t)2 * PS_WBYTES + (size_t)2 * PS_NPATCH * ROWB + (size_t)PS_NTN * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv3x3_pps_kernel<CT, ACT, EXT>;
+    auto kern = conv3x3_pps_kernel<CT, ACT, EXT, R1P>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
@@ -520,7 +545,7 @@ int dsvc_conv3x3_pps_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;          // pixel indices go through the 24-bit multiplier
     if (ntiles * nsplit < 1000) return 1;                          // small images: the general kernel's finer tiling fills the chip better
-    if (f32) return launch_pps<float, false>(st, p, ntiles, 1.f);
+    if (f32) return (d->res1 && !d->res2 && g_dsvc_opt.pps_f32 != 3) ? launch_pps<float, false, false, true>(st, p, ntiles, 1.f) : launch_pps<float, false>(st, p, ntiles, 1.f);
     const float act_slope = d->act == DSVC_ACT_NONE ? 1.f : (d->act == DSVC_ACT_RELU ? 0.f : d->slope);
     if (nsplit > 1 || d->res1 || d->pre_act != DSVC_ACT_NONE)          // output-channel split / pre-activation / residual: the extended instantiation
         return d->act == DSVC_ACT_NONE ? launch_pps<h16, false, true>(st, p, ntiles, 1.f, nsplit) : launch_pps<h16, true, true>(st, p, ntiles, act_slope, nsplit);
