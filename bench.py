@@ -389,6 +389,18 @@ def main():
                       "whole_frame_tflops": n32 / t32 * FLOP_PER_PX[2] * H_pad * W_pad / 1e12,
                       "note": "fp32 storage + v_mfma_f32_32x32x2_f32: the reference's arithmetic (PyTorch fp32); bitstreams byte-identical "
                               "to the reference's golden strings at 64/128/256 px (tests/test_gpu_parity.py)"}
+            if args.lanes > 1:
+                # ---- ... and with as many GOPs in flight as the headline leg (whole-job fp32 throughput of this GPU) ----
+                more = [make_lane(ln, "fp32") for ln in range(1, args.lanes)]
+                f32["rows"] = []
+                warm([f32] + more, 2)
+                t32n, _, _ = timed([f32] + more, n32)
+                parity["at_headline_lanes"] = {"value": n32 * args.lanes * world / t32n, "unit": "frames/s", "steps": n32, "gop_lanes": args.lanes,
+                                               "ms_per_step": 1000.0 * t32n / n32,
+                                               "whole_frame_tflops": n32 * args.lanes / t32n * FLOP_PER_PX[2] * H_pad * W_pad / 1e12}
+                del more
+                f32["rows"] = []
+                torch.cuda.empty_cache()
             if rank == 0:
                 # ---- f16 mode vs fp32 mode on the same frames (each chained on its own decoded state), un-clamped tensors ----
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -496,6 +508,7 @@ def main():
                        "lanes1_ms_per_frame": None if lanes1 is None else lanes1["ms_per_step"],
                        "parity_mode_fp32_fps": None if parity is None else parity["value"],
                        "parity_mode_fp32_roofline_frac": None if parity is None or parity["roofline"] is None else parity["roofline"]["frac"],
+                       "parity_mode_fp32_fps_at_headline_lanes": None if parity is None or "at_headline_lanes" not in parity else parity["at_headline_lanes"]["value"],
                        "roofline_frac": None if roof is None else roof["frac"]},
             "roofline": roof,
         }
