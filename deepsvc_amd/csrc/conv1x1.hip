@@ -352,7 +352,10 @@ int dsvc_conv1x1_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_des
     ConvSeg sg = p_in.seg[0];
     sg.C = ctot;                                               // total input channels select the k-step count
     const int64_t npix = (int64_t)d->B * d->H * d->W;
-    if (npix < 64 * 1024) return 1;                            // small images stay on the generic kernel
+    // 16 K pixels and up (136x240 -- the 1/8-resolution bottlenecks -- included: 96 -> 96 + residual 8.1 us streamed, 25.2 us in the general
+    // kernel; 64 -> 64 8.4 vs 11.4); the entropy-parameter nets' images (68x120) stay on the general kernel
+    static const int64_t min_px = getenv("DSVC_1X1_MIN_PX") ? atoll(getenv("DSVC_1X1_MIN_PX")) : 16 * 1024;
+    if (npix < min_px) return 1;
     ConvParams p = p_in;
     p.B = 1; p.Ho = 1; p.Wo = (int)npix;                        // flat pixel list: offsets are pixel-linear
     const int nunits = (int)((npix + 31) / 32);
