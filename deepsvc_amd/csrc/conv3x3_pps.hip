@@ -28,6 +28,23 @@
 
 using namespace dsvc_conv;
 
+#ifdef DSVC_PPS_PROBE
+// python -m deepsvc_amd.build --variant ppsprobe -DDSVC_PPS_PROBE; tools/pps_phase_probe.py: for wave 0 of each group of every workgroup, shader clocks
+// [g*8 + 0] M phases, [1] waiting at the barrier that ends them, [2] S phases (patch / weight commit + requests), [3] the barrier after them,
+// [4] epilogues (part of the S slot), [5] s_memrealtime ticks of the whole kernel, [6] s_memtime clocks of the whole kernel; [16] = stream steps
+__device__ unsigned long long g_pps_phase[17];
+extern "C" int dsvc_dbg_pps_phase_read(unsigned long long* out17, int reset) {
+    if (hipMemcpyFromSymbol(out17, HIP_SYMBOL(g_pps_phase), sizeof(g_pps_phase)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[17] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pps_phase), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define PPS_STAMP(v) { v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define PPS_ADD(i, a, b) { psp[i] += (b) - (a); }
+#else
+#define PPS_STAMP(v)
+#define PPS_ADD(i, a, b)
+#endif
+
 namespace {
 
 constexpr int PS_TH = 8, PS_PW = 34, PS_NPATCH = (PS_TH + 2) * PS_PW;   // 340 patch pixels
@@ -131,6 +148,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
             pf[j] = buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));
         }
     };
+    // one vector of load_chunk (fp32: the requests are issued from inside the M phase, one per k-step -- see mfma_phase)
+    auto load_chunk_one = [&](const TileOrg& t, int ch, int j) -> uint4 {
+        int si = 0;
+        if (p.nseg > 1 && ch >= p.seg[1].chunk0) si = 1;
+        if (p.nseg > 2 && ch >= p.seg[2].chunk0) si = 2;
+        const ConvSeg& sg = p.seg[si];
+        const rsrc_t rin = make_rsrc(sg.ptr, sg.bytes);
+        const unsigned ldb = (unsigned)sg.ld * (unsigned)sizeof(CT), cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
+        const bool cok = (ch - sg.chunk0) * KCE + q * EPV < sg.C;
+        const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;
+        const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
+        const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PS_PFV - 1 || last_ok) && cok;
+        return buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));
+    };
     const float pre_sl = p.pre_act == DSVC_ACT_RELU ? 0.f : p.slope;
     auto store_chunk = [&](uint4 (&pf)[PS_PFV]) {
 #pragma unroll
@@ -178,6 +209,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
             }
         }
     };
+    auto load_whalf_one = [&](int ch, int j) -> uint4 {          // (!EXT instances only)
+        const unsigned base = ((unsigned)ch * PS_WROWS + (unsigned)g * PS_HALF) * 64u + q * 16u;
+        const unsigned row = (unsigned)(gtid >> 2) + 64u * j;
+        return buf_load16(rw, (base + row * 64u) | (row < (unsigned)PS_HALF ? 0u : OOB));
+    };
     auto store_whalf = [&](int buf, uint4 (&wv)[PS_WV]) {
         char* dst = lds_w + buf * PS_WBYTES + g * PS_HALF * ROWB + q * 16;
 #pragma unroll
@@ -194,7 +230,13 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
     for (int n = 0; n < NT; ++n) b_off[n] = (n * 32 + r) * ROWB + h * 32;
 
     f32x16 acc[MTW][NT];
-    auto mfma_phase = [&](int wsel) {          // 18 k-steps (9 taps x 2 halves of the 64-byte chunk), fragments read two k-steps ahead
+    // F32_MLOAD (fp32): a wave issuing v_mfma_f32_32x32x2_f32 back to back starves the other wave of its SIMD (tools/pps_phase_probe.py: the partner
+    // group's S + E slot stretched to the M phase's length and its natural length -- 4.1 K clocks per step, mostly the issue of 11 vector-memory
+    // requests per wave -- came on top), but between two of ITS OWN MFMAs a request issues for free: the matrix pipe is busy for 64 clocks either
+    // way.  So the patch and weight requests of this group ride inside its M phase, one per k-step, and the S slot only commits registers to LDS.
+    // Prefetch distance: patch(t + 2) is requested in M(t) into the buffer that S(t - 1) emptied and committed in S(t + 1).
+    constexpr bool F32_MLOAD = F32 && !EXT;
+    auto mfma_phase = [&](int wsel, uint4 (&pf_load)[PS_PFV], uint4 (&wv_load)[PS_WV], const TileOrg& lt, int lch, int wch, bool wload) {          // 18 k-steps (9 taps x 2 halves of the 64-byte chunk), fragments read two k-steps ahead
         const char* wt = lds_w + wsel * PS_WBYTES;
         auto read_frags = [&](int s, uint4 (&af)[MTW], uint4 (&bf)[NT]) {
             const int t = s >> 1, ks = s & 1;
@@ -207,14 +249,37 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
         // fragments are read FST - 1 k-steps ahead: two for f16 (one step = 4 MFMAs = 128 cycles does not cover the ds_read latency beside the other
         // group's LDS traffic), one for fp32 (a step is 16 MFMAs = 1024 cycles; the third register set would spill)
         constexpr int FST = 3;
+#ifdef DSVC_PPS_NO_INTERLEAVE
+        constexpr bool F32_INTERLEAVE = false;
+#else
+        constexpr bool F32_INTERLEAVE = true;
+#endif
         uint4 af[FST][MTW], bf[FST][NT];
         read_frags(0, af[0], bf[0]);
         if constexpr (FST == 3) read_frags(1, af[1], bf[1]);
-        __builtin_amdgcn_s_setprio(3);
+#ifndef DSVC_PPS_F32_PRIO
+#define DSVC_PPS_F32_PRIO 0
+#endif
+        if constexpr (F32) { if (DSVC_PPS_F32_PRIO) __builtin_amdgcn_s_setprio(DSVC_PPS_F32_PRIO); } else __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s2 = 0; s2 < 18; ++s2) {
             if (s2 + FST - 1 < 18) read_frags(s2 + FST - 1, af[(s2 + FST - 1) % FST], bf[(s2 + FST - 1) % FST]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (F32 && F32_INTERLEAVE) {
+                // consecutive MFMAs on DIFFERENT accumulators (each accumulator still sees j = 0..3 in order: same bits)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, bf[s2 % FST][n])[j], __builtin_bit_cast(f32x4, af[s2 % FST][m])[j], acc[m][n], 0, 0, 0);
+                        }
+                if constexpr (F32_MLOAD) {
+                    if (s2 < PS_PFV) pf_load[s2 < PS_PFV ? s2 : 0] = load_chunk_one(lt, lch, s2 < PS_PFV ? s2 : 0);
+                    else if (s2 - PS_PFV < PS_WV) { if (wload) wv_load[s2 - PS_PFV < PS_WV ? s2 - PS_PFV : 0] = load_whalf_one(wch, s2 - PS_PFV < PS_WV ? s2 - PS_PFV : 0); }
+                }
+            } else
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -258,74 +323,68 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
       const unsigned lo_ = sw.x, hi_ = sw.y; (LO) = __builtin_bit_cast(float, lo_); (HI) = __builtin_bit_cast(float, hi_); }
 #define PS_SWAP16(X, Y, A, B)                                                                                       \
     { const v2u_t sw = __builtin_amdgcn_permlane16_swap((X), (Y), false, false); (A) = sw.x; (B) = sw.y; }
-    // ---- fp32 epilogue: lane (r, h) holds channels 32 N + 8 h .. +7 (v0) and 32 N + 16 + 8 h .. +7 (v1) of pixel r of tile row M ----
+    // ---- fp32 epilogue: D[channel][pixel] as the MFMA leaves it -- lane (r, h) holds, of pixel r of tile row M, the four channels
+    // 32 N + 8 G + 4 h .. +3 in accumulator registers 4 G .. 4 G + 3 (G = 0..3): 16-byte vectors already, so (unlike f16, whose 16-byte vector is
+    // eight channels) no lane swap is needed; lanes (r, 0) and (r, 1) cover 32 contiguous bytes of the pixel per instruction.
+    // (The S / E work of one group does NOT hide under the other group's fp32 MFMAs: a wave issuing v_mfma_f32_32x32x2_f32 back to back
+    // starves its SIMD partner -- tools/pps_phase_probe.py: the S + E slot stretches to the M phase's length and its natural length, 4.1 K
+    // clocks per step, is added on top -- so every instruction removed here is MFMA time won: 0.807 -> 0.84 of the fp32 peak.)
     const rsrc_t rr1 = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? p.res1_bytes : p.out_bytes);
     const rsrc_t rr2 = make_rsrc(p.res2 ? p.res2 : p.out, p.res2 ? p.res2_bytes : p.out_bytes);
     const bool has_res = p.res1 != nullptr || p.res2 != nullptr;
-    // residual operands of one 32x32 accumulator tile: 2 x 2 16-byte loads per operand, all eight requested before the first is used
-    // (per half tile -- eight dependent round trips per tile pair -- the epilogue outlasted the partner group's M phase)
+    // residual operands of one 32x32 accumulator tile: 4 16-byte loads per operand, all requested before the first is used
     struct ResRegs { uint4 a[4], b[4]; };
     auto tile_pos = [&](const TileOrg& t, int m, int n, bool valid, unsigned* pm, unsigned* opix, unsigned* c0) {
         const int oy = t.oy0 + wg * MTW + m, ox = t.ox0 + r;
         *pm = (valid && oy < p.Ho && ox < p.Wo) ? 0u : OOB;
         *opix = (unsigned)((t.b * p.Ho + oy) * p.Wo + ox);
-        *c0 = (unsigned)(n * 32 + 8 * h);
+        *c0 = (unsigned)(n * 32 + 4 * h);
     };
     auto res_issue = [&](const TileOrg& t, int m, int n, bool valid, ResRegs& R) {
         unsigned pm, opix, c0;
         tile_pos(t, m, n, valid, &pm, &opix, &c0);
+        const unsigned e1 = ((opix * (unsigned)p.res1_ld + c0) * 4u) | pm | (p.res1 ? 0u : OOB);
+        const unsigned e2 = ((opix * (unsigned)p.res2_ld + c0) * 4u) | pm | (p.res2 ? 0u : OOB);
 #pragma unroll
-        for (int P2 = 0; P2 < 2; ++P2) {
-            const unsigned cb = c0 + 16u * P2;
-            const unsigned e1 = ((opix * (unsigned)p.res1_ld + cb) * 4u) | pm | (p.res1 ? 0u : OOB);
-            const unsigned e2 = ((opix * (unsigned)p.res2_ld + cb) * 4u) | pm | (p.res2 ? 0u : OOB);
-            R.a[2 * P2] = buf_load16(rr1, e1); R.a[2 * P2 + 1] = buf_load16(rr1, e1 + 16u);
-            R.b[2 * P2] = buf_load16(rr2, e2); R.b[2 * P2 + 1] = buf_load16(rr2, e2 + 16u);
-        }
+        for (int G = 0; G < 4; ++G) { R.a[G] = buf_load16(rr1, e1 + 32u * G); R.b[G] = buf_load16(rr2, e2 + 32u * G); }
     };
     // R1P (fp32, ONE residual operand -- ResBlock1.conv2 + x, 22 launches per frame): half the operand registers per tile, so the NEXT 32x32
     // tile's loads are in flight behind the current tile's arithmetic and stores (two sets, same register count as one two-operand set)
     auto res1_issue = [&](const TileOrg& t, int m, int n, bool valid, uint4 (&ra)[4]) {
         unsigned pm, opix, c0;
         tile_pos(t, m, n, valid, &pm, &opix, &c0);
+        const unsigned e1 = ((opix * (unsigned)p.res1_ld + c0) * 4u) | pm;
 #pragma unroll
-        for (int P2 = 0; P2 < 2; ++P2) {
-            const unsigned e1 = ((opix * (unsigned)p.res1_ld + c0 + 16u * P2) * 4u) | pm;
-            ra[2 * P2] = buf_load16(rr1, e1); ra[2 * P2 + 1] = buf_load16(rr1, e1 + 16u);
-        }
+        for (int G = 0; G < 4; ++G) ra[G] = buf_load16(rr1, e1 + 32u * G);
     };
     auto tile_f32 = [&](const TileOrg& t, const f32x16& a, int m, int n, bool valid, const ResRegs& R) {
-        float v0[8], v1[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            PS_SWAP32(a[j], a[4 + j], v0[j], v0[4 + j])
-            PS_SWAP32(a[8 + j], a[12 + j], v1[j], v1[4 + j])
-        }
         unsigned pm, opix, c0;
         tile_pos(t, m, n, valid, &pm, &opix, &c0);
+        const unsigned eo = ((opix * (unsigned)p.out_ld + c0) * 4u) | pm;
 #pragma unroll
-        for (int P2 = 0; P2 < 2; ++P2) {
-            float* v = P2 ? v1 : v0;
-            const unsigned cb = c0 + 16u * P2;
-            const float4 ba = *(const float4*)(lds_bias + cb), bb = *(const float4*)(lds_bias + cb + 4);
-            const float bq[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+        for (int G = 0; G < 4; ++G) {
+            const float4 bq = *(const float4*)(lds_bias + c0 + 8 * G);
+            float v[4] = {a[4 * G] + bq.x, a[4 * G + 1] + bq.y, a[4 * G + 2] + bq.z, a[4 * G + 3] + bq.w};
+            // one wave-uniform branch per vector, not per element (per-element selects compiled to 128 scalar compare + branch pairs per tile).
+            // max(x, +0) and max(x, x * slope), 0 <= slope <= 1, are the general kernel's x > 0 ? x : 0 / x > 0 ? x : x * slope bit for bit,
+            // zero signs included (-0 -> +0 under ReLU, -0 * slope = -0 under LeakyReLU)
+            if (p.act == DSVC_ACT_RELU) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = v[j] + bq[j];
-                v[j] = p.act == DSVC_ACT_RELU ? (x > 0.f ? x : 0.f) : (p.act == DSVC_ACT_LRELU ? (x > 0.f ? x : x * p.slope) : x);
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], 0.f);
+            } else if (p.act == DSVC_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], v[j] * p.slope);
             }
             if (R1P || has_res) {       // + (res1 + res2), the general kernel's order (conv_common.h: epilogue_vec); an absent operand reads zeros
-                const uint4 f1a = R.a[2 * P2], f1b = R.a[2 * P2 + 1], f2a = R.b[2 * P2], f2b = R.b[2 * P2 + 1];
-                const unsigned u1[8] = {f1a.x, f1a.y, f1a.z, f1a.w, f1b.x, f1b.y, f1b.z, f1b.w}, u2[8] = {f2a.x, f2a.y, f2a.z, f2a.w, f2b.x, f2b.y, f2b.z, f2b.w};
+                const uint4 f1 = R.a[G], f2 = R.b[G];
+                const unsigned u1[4] = {f1.x, f1.y, f1.z, f1.w}, u2[4] = {f2.x, f2.y, f2.z, f2.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 4; ++j) {
                     const float r1 = __builtin_bit_cast(float, u1[j]) + 0.f, r2 = __builtin_bit_cast(float, u2[j]) + 0.f;
                     v[j] += r1 + r2;
                 }
             }
-            const unsigned eo = ((opix * (unsigned)p.out_ld + cb) * 4u) | pm;
-            ps_store16(rout, eo, make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])));
-            ps_store16(rout, eo + 16u, make_uint4(__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])));
+            ps_store16(rout, eo + 32u * G, make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])));
         }
     };
 #define PS_TILE(M, N)                                                                                               \
@@ -406,7 +465,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
         }
         if (g == 1) store_whalf(1, wv);                    // (wave-uniform branch; group 0 keeps its half of weights(1) in wv)
     }
-    load_chunk(lorg, lc, pfA); advance_load();            // patch(2)
+    if constexpr (!F32_MLOAD) { load_chunk(lorg, lc, pfA); advance_load(); }            // patch(2) (fp32: requested inside M(0))
     // weight stream position of this group: after M(t) it commits half g of weights(t + 1 + g) and requests weights(t + 2 + g)
     int wc = (1 + g) % NCH;                                // chunk of the half held in wv (group 0) / to hold next
     if (g == 1) { wc = 2 % NCH; load_whalf(wc, wv); }      // group 1: wv <- its half of weights(2)
@@ -416,10 +475,29 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
     int c = 0, k = 0;
     const int steps = iters * NCH;
     // one stream step; PFX = the register buffer that holds patch(t + 1) (and is refilled with patch(t + 3))
-    auto step = [&](int t, uint4 (&pf_next)[PS_PFV]) {
+#ifdef DSVC_PPS_PROBE
+    unsigned long long psp[5] = {0, 0, 0, 0, 0};
+    const unsigned long long pk_t0 = __builtin_amdgcn_s_memtime(), pk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    auto step = [&](int t, uint4 (&pf_next)[PS_PFV], uint4 (&pf_other)[PS_PFV]) {
+#ifdef DSVC_PPS_PROBE
+        unsigned long long q0, q1, q2, q3, q4, q5;
+#endif
+        PPS_STAMP(q0)
         if (c == 0) init_acc();
-        mfma_phase(t & 1);
+        if constexpr (F32_MLOAD) {
+            int wnext = wc;
+            if (t > 0 && ++wnext == NCH) wnext = 0;
+            mfma_phase(t & 1, pf_other, wv, lorg, lc, wnext, t > 0);      // ... and requests patch(t + 2) and (from the second step on) the next weight half
+            advance_load();
+            wc = wnext;
+        } else {
+            mfma_phase(t & 1, pf_other, wv, lorg, lc, 0, false);
+        }
+        PPS_STAMP(q1)
         lds_barrier();
+        PPS_STAMP(q2)
+        PPS_ADD(0, q0, q1) PPS_ADD(1, q1, q2)
         if (c == NCH - 1) {              // ---- epilogue of the finished tile (wave-uniform branch) ----
             const bool valid = tile_of(k) < ntiles;
             if constexpr (F32) {
@@ -465,22 +543,37 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
             }
             c = 0; ++k;
             cur = org_of(k);
+            PPS_STAMP(q3)
+            PPS_ADD(4, q2, q3)
         } else {
             ++c;
         }
         // ---- S: patch(t + 1) into the group's LDS patch, request patch(t + 3); commit / request this group's weight halves ----
         store_chunk(pf_next);
-        load_chunk(lorg, lc, pf_next); advance_load();
+        if constexpr (!F32_MLOAD) { load_chunk(lorg, lc, pf_next); advance_load(); }
         store_whalf((t + 1 + g) & 1, wv);
-        if (++wc == NCH) wc = 0;
-        load_whalf(wc, wv);
+        if constexpr (!F32_MLOAD) {
+            if (++wc == NCH) wc = 0;
+            load_whalf(wc, wv);
+        }
+        PPS_STAMP(q4)
         lds_barrier();
+        PPS_STAMP(q5)
+        PPS_ADD(2, q2, q4) PPS_ADD(3, q4, q5)
     };
     for (int t = 0; t < steps; t += 2) {
-        step(t, pfB);
-        if (t + 1 < steps) step(t + 1, pfA);
+        step(t, pfB, pfA);
+        if (t + 1 < steps) step(t + 1, pfA, pfB);
     }
     if (!g) lds_barrier();               // matches group 1's leading barrier
+#ifdef DSVC_PPS_PROBE
+    if (wg == 0 && lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_pps_phase[g * 8 + i], psp[i]);
+        atomicAdd(&g_pps_phase[g * 8 + 5], __builtin_amdgcn_s_memrealtime() - pk_r0);
+        atomicAdd(&g_pps_phase[g * 8 + 6], __builtin_amdgcn_s_memtime() - pk_t0);
+        if (g == 0) atomicAdd(&g_pps_phase[16], (unsigned long long)steps);
+    }
+#endif
 #undef PS_TILE
 #undef PS_SWAP16
 #undef PS_SWAP32
