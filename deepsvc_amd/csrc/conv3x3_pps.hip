@@ -625,9 +625,7 @@ int dsvc_conv3x3_pps_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv
         if (!g_dsvc_opt.pps_f32) return 1;
         if (d->res1 && (d->res1_dtype != DSVC_F32 || !ps_vec16_ok(d->res1, d->res1_ld, 4))) return 1;
         if (d->res2 && (d->res2_dtype != DSVC_F32 || !ps_vec16_ok(d->res2, d->res2_ld, 4))) return 1;
-        // two residual operands: 16 dependent-latency loads per tile pair in the epilogue -- measured slower than the general kernel
-        // (1375 vs 1337 us, tools/bench_pps.py); forced by pps_f32 = 2 (tests)
-        if (d->res1 && d->res2 && g_dsvc_opt.pps_f32 < 2) return 1;
+        // (two residual operands: 1315 vs 1328 us in the general kernel since the requests moved into the M phase -- taken too)
     } else {                                                       // f16: pre-activation and ONE f16 residual are run-time parameters
         if (d->res2) return 1;
         if (d->res1 && (d->res1_dtype != DSVC_F16 || !ps_vec16_ok(d->res1, d->res1_ld, 2))) return 1;
