@@ -327,7 +327,7 @@ def main():
             al = sum(by[str(k)]["algorithmic_bytes_per_launch"] * c for k, c in hist.items() if c) / n
         else:
             tr, al = sec.get("hbm_bytes_per_launch_corrected"), sec.get("algorithmic_bytes_per_launch")
-        src_fp = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deepsvc_amd", "csrc", f), "rb").read() for f in ("conv3x3_pp.hip", "conv_mfma.hip", "conv_common.h"))).hexdigest()[:16]
+        src_fp = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deepsvc_amd", "csrc", f), "rb").read() for f in ("conv3x3_pp.hip", "conv3x3_pps.hip", "conv_mfma.hip", "conv_common.h"))).hexdigest()[:16]
         stale = pmc.get("kernel_sources_sha256_16") not in (None, src_fp)
         return tr, {"traffic_over_algorithmic": tr / al if tr and al else None, "traffic_algorithmic_bytes": al,
                     "traffic_pmc_collected_on": {"commit": pmc.get("commit"), "kernel_sources_sha256_16": pmc.get("kernel_sources_sha256_16")},

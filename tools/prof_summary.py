@@ -31,9 +31,10 @@ def short(n):
     m = re.match(r"_ZN12_GLOBAL__N_116conv_mfma_kernelI(DF16_|f)Li(\d)ELi(\d)ELb(\d)ELb(\d)ELi(\d)EEEvN9dsvc", n)
     if m:
         n = f"conv_mfma_kernel<{'f16' if m.group(1) == 'DF16_' else 'f32'}, MT={m.group(2)}, NT={m.group(3)}, FAST={m.group(4)}, REGEPI={m.group(5)}, PF={m.group(6)}>"
-    m = re.match(r"_ZN12_GLOBAL__N_118conv3x3_pps_kernelI(DF16_|f)Lb(\d)EEEvN9dsvc", n)
+    m = re.match(r"_ZN12_GLOBAL__N_118conv3x3_pps_kernelI(DF16_|f)((?:Lb\dE)+)EEvN9dsvc", n)
     if m:
-        n = f"conv3x3_pps_kernel<{'f16' if m.group(1) == 'DF16_' else 'float'}, ACT={m.group(2)}>"
+        flags = re.findall(r"Lb(\d)E", m.group(2)) + ["0", "0", "0"]
+        n = f"conv3x3_pps_kernel<{'f16' if m.group(1) == 'DF16_' else 'float'}, ACT={flags[0]}, EXT={flags[1]}, R1P={flags[2]}>"
     return n
 
 
@@ -202,7 +203,7 @@ if all(os.path.exists(p) for p in (pf, pw, ps)):
     import hashlib
     import subprocess
     csrc = os.path.join(ROOT, "deepsvc_amd", "csrc")
-    full["kernel_sources_sha256_16"] = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("conv3x3_pp.hip", "conv_mfma.hip", "conv_common.h"))).hexdigest()[:16]
+    full["kernel_sources_sha256_16"] = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("conv3x3_pp.hip", "conv3x3_pps.hip", "conv_mfma.hip", "conv_common.h"))).hexdigest()[:16]
     try:
         head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
         dirty = subprocess.call(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "deepsvc_amd/csrc"]) != 0
