@@ -612,7 +612,7 @@ int dsvc_conv3x3_pps_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv
     //  pass computes 32 padding columns; 64->128 @272x480 29 / 30: only the first is on by default, pps = 2 forces the others for the tests)
     const bool split_ok = !f32 && ((d->Cout == 128 && p_in.nchunks >= 4) || (g_dsvc_opt.pps >= 2 && (d->Cout == 96 || d->Cout == 128) && p_in.nchunks >= 2));
     const int nsplit = d->Cout == 64 ? 1 : (split_ok ? 2 : 0);
-    if (nsplit == 0 || (nsplit == 1 && p_in.nchunks < 3)) return 1;
+    if (nsplit == 0 || (nsplit == 1 && p_in.nchunks < (f32 ? 2 : 3))) return 1;     // (fp32 has no resident-weights sibling: two chunks -- 32 -> 64 -- stream as well)
     const int esz = f32 ? 4 : 2, epv = f32 ? 4 : 8, dt = f32 ? DSVC_F32 : DSVC_F16;
     for (int s = 0; s < p_in.nseg; ++s) {                          // every pixel's chunk row is an aligned run of 16-byte vectors
         const ConvSeg& sg = p_in.seg[s];

@@ -467,6 +467,8 @@ def test_streamed_weights_pp_kernel_matches_general_kernel(segs, cout, H, W, pre
     ((64,), 264, 1056, 0, 0, 2),          # FeatureExtraction's last block (modules.py:361-374): + x + conv1(x)
     ((64, 64), 256, 1024, 0, 2, 0),       # two segments, eight chunks, LeakyReLU
     ((64, 4), 256, 1024, 0, 0, 1),        # a 4-channel segment = one valid quarter of a chunk (fp32 mode takes 3-channel frames unpacked: C % 4 != 0 stays general)
+    ((32,), 256, 1024, 0, 2, 0),          # two chunks (UNet.conv2's first conv 32 -> 64): the weight-buffer parity alternates every step
+    ((16, 16), 250, 1000, 0, 0, 1),       # two one-chunk segments, ragged tiles, + residual
 ])
 def test_streamed_weights_pp_kernel_fp32_is_bit_identical_to_the_general_kernel(segs, H, W, pre, act, nres):
     """The fp32 instantiation of csrc/conv3x3_pps.hip -- the parity mode's arithmetic: v_mfma_f32_32x32x2_f32 over 16-channel chunks,

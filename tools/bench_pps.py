@@ -35,7 +35,7 @@ for segs, cout, H, W, act in SHAPES:
 
 # ---- fp32 (parity) mode: the dominant 3x3 64 -> 64 shape and its epilogue variants ----
 ops.set_precision("fp32")
-for name, segs, pre, act, nres in (("plain", (64,), 0, 0, 0), ("pre+act", (64,), 1, 1, 0), ("+res", (64,), 0, 0, 1), ("+2 res", (64,), 0, 0, 2), ("64+64", (64, 64), 0, 0, 0)):
+for name, segs, pre, act, nres in (("plain", (64,), 0, 0, 0), ("pre+act", (64,), 1, 1, 0), ("+res", (64,), 0, 0, 1), ("+2 res", (64,), 0, 0, 2), ("64+64", (64, 64), 0, 0, 0), ("32 (two chunks)", (32,), 0, 2, 0), ("32+32", (32, 32), 0, 2, 0)):
     H, W = 1088, 1920
     torch.manual_seed(0)
     m = Conv2d(sum(segs), 64, 3, 1, 1).to(dev)
