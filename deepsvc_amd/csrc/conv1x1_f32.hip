@@ -67,8 +67,14 @@ __global__ void __launch_bounds__(256) conv1x1_f32_kernel(const ConvParams p, in
             const int v = i * 64 + lane, px = v / PPI, pc = v - px * PPI;
             const unsigned pix = (unsigned)u * 32 + px;
             const unsigned m = (uok && pix < npix) ? 0u : OOB;
-            g[i] = pc < pp0 ? buf_load16(rin, (pix * pitch + (unsigned)pc * 16u) | m)
-                            : buf_load16(rin1, (pix * pitch1 + (unsigned)(pc - pp0) * 16u) | m);
+            // (two segments: BOTH descriptors are read, each lane masked out of the one that is not its own -- a per-lane choice of descriptor
+            //  compiles to a waterfall loop over the descriptor values around every load)
+            if (!two) g[i] = buf_load16(rin, (pix * pitch + (unsigned)pc * 16u) | m);
+            else {
+                const uint4 a = buf_load16(rin, (pix * pitch + (unsigned)pc * 16u) | m | (pc < pp0 ? 0u : OOB));
+                const uint4 b = buf_load16(rin1, (pix * pitch1 + (unsigned)(pc - pp0) * 16u) | m | (pc < pp0 ? OOB : 0u));
+                g[i] = make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w);
+            }
         }
     };
     auto load_gr = [&](int u, uint4 (&g)[NLO]) {                     // residual rows in the layout of the output rows
