@@ -332,6 +332,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             const rsrc_t rs = make_rsrc(sg.ptr, sg.bytes);
             const unsigned img0 = (unsigned)b * (unsigned)p.H * (unsigned)p.W;
             const int cq = c0 + q * 4;
+            // a 16-byte-aligned segment of whole 4-channel quarters beside the narrow ones (the 64-channel segment of 3+64+3 -> 96): one
+            // 16-byte request per pixel quarter instead of four dword requests (wave-uniform choice per segment)
+            const bool seg_vec = sg.vec_ok && (sg.C % 4) == 0;
             int py = py0, px = px0;
             for (int base = pix0; base < npatch; base += 64 * PBN) {
                 unsigned u[PBN][4];
@@ -342,9 +345,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     lr[j] = lds_row(py, px);
                     const bool inb = base + 64 * j < npatch && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                     const unsigned e0 = ((img0 + (unsigned)iy * p.W + (unsigned)ix) * (unsigned)sg.ld + (unsigned)cq) * 4u;
+                    if (seg_vec) {
+                        const uint4 t = buf_load16(rs, (inb && cq < sg.C) ? e0 : OOB);
+                        u[j][0] = t.x; u[j][1] = t.y; u[j][2] = t.z; u[j][3] = t.w;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        u[j][e] = __builtin_amdgcn_raw_buffer_load_b32(rs, (inb && cq + e < sg.C) ? e0 + 4u * e : OOB, 0, 0);
+                        for (int e = 0; e < 4; ++e)
+                            u[j][e] = __builtin_amdgcn_raw_buffer_load_b32(rs, (inb && cq + e < sg.C) ? e0 + 4u * e : OOB, 0, 0);
+                    }
                     px += dpx; py += dpy;
                     if (px >= PW) { px -= PW; ++py; }
                 }

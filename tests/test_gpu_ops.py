@@ -512,7 +512,8 @@ def test_streamed_weights_pp_kernel_fp32_is_bit_identical_to_the_general_kernel(
     ((2, 3), 64, 3, 1, 130, 250, 0),          # RefineNet(mv) first conv on cat[mv, ref] (modules.py:307)
     ((3, 2, 3), 64, 5, 2, 128, 256, 0),       # mv codec g_a[0] on cat[cur, mv, ref] (image_model.py:53-66), stride 2
     ((3, 3, 2), 32, 7, 1, 68, 130, 1),        # MEBasic's first conv on cat[im1, warped, flow] (modules.py:127)
-    ((64, 3), 64, 3, 1, 130, 250, 0),         # a full segment beside a narrow one: only the narrow chunk skips
+    ((64, 3), 64, 3, 1, 130, 250, 0),         # a full segment beside a narrow one: only the narrow chunk skips; the full one is staged with 16-byte requests
+    ((3, 64, 3), 96, 5, 2, 128, 256, 0),      # the residual codec's g_a[0] on cat[cur, feature, predict] (image_model.py:53-66)
     ((5,), 64, 3, 1, 40, 70, 2),              # five channels: second k step partly valid
 ])
 def test_fp32_zero_k_slots_skipped_bit_identically(segs, cout, k, stride, H, W, act):

@@ -9,7 +9,7 @@ from deepsvc_amd.modules import Conv2d  # noqa: E402
 ops.set_precision("fp32")
 dev = "cuda:0"
 H, W = 1088, 1920
-for segs, cout, k, stride in [((3,), 64, 3, 1), ((2, 3), 64, 3, 1), ((3, 2, 3), 64, 5, 2), ((3, 3, 2), 32, 7, 1), ((64, 3), 64, 3, 1)]:
+for segs, cout, k, stride in [((3,), 64, 3, 1), ((2, 3), 64, 3, 1), ((3, 2, 3), 64, 5, 2), ((3, 3, 2), 32, 7, 1), ((64, 3), 64, 3, 1), ((3, 64, 3), 96, 5, 2)]:
     torch.manual_seed(0)
     m = Conv2d(sum(segs), cout, k, stride, k // 2).to(dev)
     xs = [ops.Act(torch.randn((1, H, W, c), device=dev)) for c in segs]
