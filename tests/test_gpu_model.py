@@ -543,3 +543,40 @@ def test_frame_programs_equal_launch_by_launch_issue():
             assert not torch.equal(before, after), "the replayed D2 segment ignored the weight edit"
         finally:
             ops.set_precision("fp32")
+
+
+def test_fp32_specialised_kernels_leave_every_bit_of_a_frame_alone():
+    """fp32 mode's specialised kernels (streamed-weights 3x3, streaming 1x1, vector-ALU heads, zero-k-slot skipping, small-image patch
+    prefetch) are each asserted bit-identical to the general kernel per launch (tests/test_gpu_ops.py); here the same at the level the
+    reference is compared at: two chained P-frames at 256x1024 (1024 tiles: every one of them takes launches), all options on vs all off --
+    identical strings, bit-identical decoded tensors; and the launch counters prove the options changed which kernels ran."""
+    from deepsvc_amd import ops, synth
+    H, W = 256, 1024
+    fr = [f.to(DEV) for f in synth.make_frames(H, W, 3)]
+    sms = [None] + [synth.make_sm_fea(H, W, t).to(DEV) for t in (1, 2)]
+    OPTS = ("pps_f32", "conv1x1_f32", "head_f32", "skip_zero_k", "small_pf")
+    ops.set_precision("fp32")
+    outs, counts = {}, {}
+    for name, val in (("specialised", 1), ("general", 0)):
+        old = {k: ops.set_option(k, val) for k in OPTS}
+        try:
+            c0 = {k: ops.get_counter(k) for k in ("conv3x3_pps", "conv1x1", "conv_head")}
+            m = synth.make_model("W0"); m.update(force=True); m = m.to(DEV)
+            rows, ref, feat = [], fr[0], None
+            for t in (1, 2):
+                mv, res = m.compress(ref, fr[t], sms[t], feat)
+                mv, res = dict(mv.items()), dict(res.items())
+                feat, ref, warped, predict = m.decompress(ref, mv, res, sms[t], feat)
+                rows.append((mv["strings"], res["strings"], feat.float().clone(), ref.clone(), warped.clone(), predict.clone()))
+            outs[name] = rows
+            counts[name] = {k: ops.get_counter(k) - v for k, v in c0.items()}
+        finally:
+            for k, v in old.items():
+                ops.set_option(k, v)
+    print(f"[fp32 kernel selection] launches per two frames, specialised: {counts['specialised']}, general: {counts['general']}")
+    assert all(v > 0 for v in counts["specialised"].values()), counts
+    assert all(v == 0 for v in counts["general"].values()), counts
+    for t, (a, b) in enumerate(zip(outs["specialised"], outs["general"]), 1):
+        assert a[0] == b[0] and a[1] == b[1], f"frame {t}: strings differ between kernel selections"
+        for x, y, what in zip(a[2:], b[2:], ("feature", "recon", "warped", "predict")):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"frame {t}: {what} differs between kernel selections"
