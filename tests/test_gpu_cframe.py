@@ -140,3 +140,69 @@ def test_c_frame_api_equals_the_python_layer_in_f16_mode(tmp_path):
             assert np.array_equal(got["recon"][t - 1], ref.cpu().numpy()), f"frame {t}: decoded frames differ"
     finally:
         ops.set_precision("fp32")
+
+
+def test_c_frame_api_refuses_malformed_blobs(tmp_path):
+    """dsvc_pframe_program_load on damaged blobs: every truncation point sampled, a wrong magic / version / ABI size, a non-padded frame size,
+    table counts and payload offsets beyond the file, tensors and CDF tables pointing outside the blob -- each one must come back as a
+    negative status with a message (never a crash, never a handle), and the intact blob must still load afterwards."""
+    import ctypes
+    import struct
+    from deepsvc_amd import _native as N
+    path, n = _export("fp32", 64, 64, tmp_path)
+    blob = open(path, "rb").read()
+    L = ctypes.CDLL(N.LIB_PATH)
+    L.dsvc_last_error.restype = ctypes.c_char_p
+    L.dsvc_pframe_program_load.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    L.dsvc_pframe_program_destroy.argtypes = [ctypes.c_void_p]
+
+    def load(b):
+        h = ctypes.c_void_p()
+        rc = L.dsvc_pframe_program_load(bytes(b), len(b), 0, ctypes.byref(h))
+        return rc, h, (L.dsvc_last_error() or b"").decode()
+
+    def refused(b, what):
+        rc, h, msg = load(b)
+        assert rc < 0 and not h.value and msg, f"{what}: rc {rc}, handle {h.value}, message {msg!r}"
+
+    HEAD = struct.Struct("<8s8I2Q2IQ")                       # csrc/pframe_program.cpp: BlobHead (72 bytes)
+    assert HEAD.size == 72
+    f = list(HEAD.unpack_from(blob))
+    magic, version, precision, H, W, n_tensors, n_programs, n_codecs, op_size, a0, a1, fch, fes, payload_off = f
+    assert magic == b"DSVCPRG1" and (H, W) == (64, 64)
+
+    def with_head(**kw):
+        g = dict(magic=magic, version=version, precision=precision, H=H, W=W, n_tensors=n_tensors, n_programs=n_programs, n_codecs=n_codecs,
+                 op_size=op_size, a0=a0, a1=a1, fch=fch, fes=fes, payload_off=payload_off)
+        g.update(kw)
+        return HEAD.pack(*[g[k] for k in ("magic", "version", "precision", "H", "W", "n_tensors", "n_programs", "n_codecs", "op_size", "a0", "a1", "fch", "fes", "payload_off")]) + blob[72:]
+
+    for cut in [0, 7, 40, 71, 72, 100, payload_off - 1, payload_off, payload_off + 17, len(blob) // 3, len(blob) // 2, len(blob) - 4096, len(blob) - 1]:
+        refused(blob[:max(cut, 0)], f"truncated to {cut} bytes")
+    refused(with_head(magic=b"DSVCPRG2"), "magic")
+    refused(with_head(version=2), "version")
+    refused(with_head(op_size=op_size + 8), "ABI op size")
+    refused(with_head(H=72), "frame height not a multiple of 64")
+    refused(with_head(precision=7), "precision")
+    refused(with_head(n_codecs=3), "codec count")
+    refused(with_head(n_tensors=n_tensors + (1 << 20)), "tensor table beyond the payload offset")
+    refused(with_head(n_programs=n_programs + (1 << 20)), "program table beyond the payload offset")
+    refused(with_head(payload_off=len(blob) + 1), "payload offset beyond the file")
+    # first tensor: data beyond the blob / absurd size
+    bad = bytearray(blob)
+    struct.pack_into("<Qq", bad, 72, 1 << 20, len(blob))
+    refused(bad, "tensor data outside the blob")
+    bad = bytearray(blob)
+    struct.pack_into("<Qq", bad, 72, 1 << 40, 0)
+    refused(bad, "tensor of 2^40 bytes")
+    # first codec: a CDF table pointing outside the payload (BlobCodec = 192 bytes: 16 uint32, 4 x 16-byte refs, 2 x 32-byte tables)
+    codec0 = 72 + 16 * n_tensors + 48 * n_programs
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, codec0 + 64 + 64 + 8, len(blob))          # tables[0].cdf_off
+    refused(bad, "CDF table outside the blob")
+    bad = bytearray(blob)
+    struct.pack_into("<II", bad, codec0 + 64, 9, 1 << 30)                  # refs[0] = {kind 9, tensor index 2^30}
+    refused(bad, "codec buffer reference")
+    rc, h, msg = load(blob)
+    assert rc == 0 and h.value, f"the intact blob no longer loads: {msg}"
+    L.dsvc_pframe_program_destroy(h)
