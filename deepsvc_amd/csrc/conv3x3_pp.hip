@@ -141,7 +141,17 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
 //     blocks cb = 2G and 2G + 1 leaves every lane with the 8 CONSECUTIVE channels 32G + 8*sigma(q) .. +7 -- 16 bytes of the pixel's
 //     64-byte channel group, at byte offset 16*sigma(q): four lanes write 64 contiguous bytes, and the packed tile is at the same
 //     time the B operand (k-block q) of the fused 1x1 conv.
-template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false>
+//
+// QC ("quad-contiguous" epilogue, round 5): in the layouts above the four lanes that cover the 64 contiguous bytes of a pixel are 16 lanes
+// apart (the MFMA puts the pixel index in the LOW lane bits), so the four ADJACENT lanes of every quad of a store / residual-load
+// instruction touch four different cache lines.  The texture addresser works through a 16-byte-per-lane instruction one quad per clock and
+// merges only what a quad holds: 64 separate 16-byte accesses instead of 16 accesses of 64 bytes -- 64 clocks of the CU's one address path per
+// instruction instead of 16.  That fits the measured E phases: (8 stores + 8 loads per residual operand) x 64 clocks x the 4 waves of a
+// group = 2048 / 4096 / 6144 clocks against 2190-2900 / 4730-4800 / 7690-8190 measured for 0 / 1 / 2 residual operands.
+// With QC the packed vectors change lanes once more on their way out -- lane 4*pixel + piece, one ds_permute_b32 per dword: the LDS
+// crossbar, no LDS memory -- so that a quad writes 64 contiguous bytes; residual vectors are loaded in that layout and pulled back with
+// ds_bpermute_b32.  Pure data movement: results are bit-identical to QC = false (tests/test_gpu_ops.py).
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false, bool QC = false>
 __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
                                                               float pre_slope) {
     DSVC_F16_SAT();
@@ -166,6 +176,18 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     const int j16 = lane & 15, q16 = lane >> 4;
     const int rho16 = j16 < 4 ? 2 * j16 + 1 : (j16 < 12 ? 2 * (j16 - 4) : 2 * (j16 - 12) + 9);
     const int sig16 = q16 == 1 ? 2 : (q16 == 2 ? 1 : q16);
+    // QC: byte address (lane x 4) of the lane that holds THIS lane's (pixel, 16-byte piece) in the quad-contiguous layout lane = 4*pixel + piece
+    const int qc_addr = 4 * (M16 ? 4 * rho16 + sig16 : 4 * (lane & 15) + 2 * ((lane >> 4) & 1) + (lane >> 5));
+    auto to_qc = [&](uint4 v) -> uint4 {        // epilogue layout -> quad-contiguous (push)
+        if constexpr (!QC) return v;
+        return make_uint4((unsigned)__builtin_amdgcn_ds_permute(qc_addr, (int)v.x), (unsigned)__builtin_amdgcn_ds_permute(qc_addr, (int)v.y),
+                          (unsigned)__builtin_amdgcn_ds_permute(qc_addr, (int)v.z), (unsigned)__builtin_amdgcn_ds_permute(qc_addr, (int)v.w));
+    };
+    auto from_qc = [&](uint4 v) -> uint4 {      // quad-contiguous -> epilogue layout (pull)
+        if constexpr (!QC) return v;
+        return make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(qc_addr, (int)v.x), (unsigned)__builtin_amdgcn_ds_bpermute(qc_addr, (int)v.y),
+                          (unsigned)__builtin_amdgcn_ds_bpermute(qc_addr, (int)v.z), (unsigned)__builtin_amdgcn_ds_bpermute(qc_addr, (int)v.w));
+    };
     auto perm_row = [](int row) {               // M16: LDS position of weight row `row` inside its 16-row block (rho of the block index)
         if constexpr (!M16) return row;
         const int i = row & 15;
@@ -331,9 +353,9 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     // M16 memory layout of a tile row: lane (j, q) <-> pixel 16*half + rho(j), bytes 16*sigma(q) .. +15 of the 64-byte channel group G
     auto row_off16 = [&](const TileOrg& t, int pb, int ld, bool valid) -> unsigned {
         const int oy = t.oy0 + wg * MTW + (pb >> 1);                                  // scalar
-        const int px = 16 * (pb & 1) + rho16;
+        const int px = 16 * (pb & 1) + (QC ? lane >> 2 : rho16);
         const unsigned pix = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0) + px;
-        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + 16 * sig16) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
+        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + 16 * (QC ? lane & 3 : sig16)) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
     };
 
     // epilogue lane roles (after the half-swap): pixel r of the tile row, channels 16*P + 8*h .. +7 of the N-tile
@@ -345,9 +367,9 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     // i.e. 4 lanes cover 64 contiguous bytes of a pixel and one instruction touches 16 cache lines instead of 32.
     auto row_off = [&](const TileOrg& t, int m, int ld, bool valid, int half) -> unsigned {
         const int oy = t.oy0 + wg * MTW + m;                                          // scalar
-        const int px = (r & 15) + 16 * half;
+        const int px = (QC ? lane >> 2 : r & 15) + 16 * half;
         const unsigned pix = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0) + px;
-        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + 32 * (r >> 4) + 16 * h) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
+        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + (QC ? 16 * (lane & 3) : 32 * (r >> 4) + 16 * h)) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
     };
     uint4 res[MTW * NT * 2];
     auto load_res = [&](const TileOrg& t, bool valid, int m0 = 0, int m1 = MTW) {
@@ -532,16 +554,16 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
             _Pragma("unroll") for (int v = 0; v < 4; ++v) { lo[v] = lrelu_f(lo[v], act_slope); hi[v] = lrelu_f(hi[v], act_slope); } \
         }                                                                                                           \
         if constexpr (HAS_R1) {                                                                                     \
-            const uint4 ra = res[PB * NT + G];                                                                      \
+            const uint4 ra = from_qc(res[PB * NT + G]);                                                             \
             lo[0] += h16_lo(ra.x); lo[1] += h16_hi(ra.x); lo[2] += h16_lo(ra.y); lo[3] += h16_hi(ra.y);             \
             hi[0] += h16_lo(ra.z); hi[1] += h16_hi(ra.z); hi[2] += h16_lo(ra.w); hi[3] += h16_hi(ra.w);             \
             if constexpr (HAS_R2) {                                                                                 \
-                const uint4 ca = buf_load16(rr2, o_r216[PB] + 64 * G);                                              \
+                const uint4 ca = from_qc(buf_load16(rr2, o_r216[PB] + 64 * G));                                     \
                 lo[0] += h16_lo(ca.x); lo[1] += h16_hi(ca.x); lo[2] += h16_lo(ca.y); lo[3] += h16_hi(ca.y);         \
                 hi[0] += h16_lo(ca.z); hi[1] += h16_hi(ca.z); hi[2] += h16_lo(ca.w); hi[3] += h16_hi(ca.w);         \
             }                                                                                                       \
         }                                                                                                           \
-        buf_store16(rout, o_out16[PB] + 64 * G, make_uint4(pk_h16(lo[0], lo[1]), pk_h16(lo[2], lo[3]), pk_h16(hi[0], hi[1]), pk_h16(hi[2], hi[3]))); \
+        buf_store16(rout, o_out16[PB] + 64 * G, to_qc(make_uint4(pk_h16(lo[0], lo[1]), pk_h16(lo[2], lo[3]), pk_h16(hi[0], hi[1]), pk_h16(hi[2], hi[3])))); \
     }
             PP16_OUT(0, 0) PP16_OUT(0, 1) PP16_OUT(1, 0) PP16_OUT(1, 1) PP16_OUT(2, 0) PP16_OUT(2, 1) PP16_OUT(3, 0) PP16_OUT(3, 1)
 #undef PP16_OUT
@@ -578,7 +600,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
             _Pragma("unroll") for (int j = 0; j < 8; ++j) { v0[j] = lrelu_f(v0[j], act_slope); v1[j] = lrelu_f(v1[j], act_slope); } \
         }                                                                                                           \
         if constexpr (HAS_R1) {                                                                                     \
-            const uint4 ra = res[(M * NT + N) * 2], rb = res[(M * NT + N) * 2 + 1];                                 \
+            const uint4 ra = from_qc(res[(M * NT + N) * 2]), rb = from_qc(res[(M * NT + N) * 2 + 1]);               \
             const unsigned ma[4] = {ra.x, ra.y, ra.z, ra.w}, mb[4] = {rb.x, rb.y, rb.z, rb.w};                      \
             unsigned xa[4], xb[4];                                                                                  \
             _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(ma[d], mb[d], xa[d], xb[d])                        \
@@ -587,7 +609,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
                 v1[2 * j] += h16_lo(xb[j]); v1[2 * j + 1] += h16_hi(xb[j]); \
             }                                                                                                       \
             if constexpr (HAS_R2) {                                                                                 \
-                const uint4 ca = buf_load16(rr2, o_r2[M][0] + 64 * N), cb = buf_load16(rr2, o_r2[M][1] + 64 * N);   \
+                const uint4 ca = from_qc(buf_load16(rr2, o_r2[M][0] + 64 * N)), cb = from_qc(buf_load16(rr2, o_r2[M][1] + 64 * N));   \
                 const unsigned na[4] = {ca.x, ca.y, ca.z, ca.w}, nb[4] = {cb.x, cb.y, cb.z, cb.w};                  \
                 unsigned ya[4], yb[4];                                                                              \
                 _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(na[d], nb[d], ya[d], yb[d])                    \
@@ -600,8 +622,8 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
         unsigned s0[4], s1[4];                                                                                      \
         _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                               \
             SWAP16(pk_h16(v0[2 * d], v0[2 * d + 1]), pk_h16(v1[2 * d], v1[2 * d + 1]), s0[d], s1[d])             \
-        buf_store16(rout, o_out[M][0] + 64 * N, make_uint4(s0[0], s0[1], s0[2], s0[3]));                            \
-        buf_store16(rout, o_out[M][1] + 64 * N, make_uint4(s1[0], s1[1], s1[2], s1[3]));                            \
+        buf_store16(rout, o_out[M][0] + 64 * N, to_qc(make_uint4(s0[0], s0[1], s0[2], s0[3])));                     \
+        buf_store16(rout, o_out[M][1] + 64 * N, to_qc(make_uint4(s1[0], s1[1], s1[2], s1[3])));                     \
     }
             if constexpr (POST) {
                 static_assert(!POST || NT == 2, "fused 1x1: 64 -> 64 channels");
@@ -664,20 +686,23 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     if (!g) lds_barrier();               // matches group 1's leading barrier
 }
 
-template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false>
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false, bool QC = false>
 int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, float pre_slope) {
+    if constexpr (!QC && !HEAD) {               // option "pp_qc": quad-contiguous epilogue (see the kernel's header comment)
+        if (g_dsvc_opt.pp_qc) return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, true>(st, p, ntiles, act_slope, pre_slope);
+    }
     if constexpr (!M16 && !HEAD) {
         // option "pp16": 0 = 32x32x16 everywhere, 2 = 16x16x32 everywhere but the narrow heads, 1 (default) = where it measured faster
         // on the same box (tools/bench_pp16.py, 1088x1920, three interleaved rounds): one residual 187 -> 179 us, fused 1x1 tail
         // 212 -> 202 us; slower or equal elsewhere (plain 152 -> 153, pre + act 165 -> 174, two residuals 235 -> 254, 64 -> 32 99 -> 103)
         const bool faster16 = NCH == 2 && NT == 2 && !PRE && HAS_R1 && !HAS_R2;
         if (g_dsvc_opt.pp16 == 2 || (g_dsvc_opt.pp16 == 1 && faster16))
-            return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, true>(st, p, ntiles, act_slope, pre_slope);
+            return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, true, QC>(st, p, ntiles, act_slope, pre_slope);
     }
     const size_t lds = (size_t)NCH * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)2 * NT * 32 * sizeof(float) +
                        (POST ? (size_t)NT * NT * 32 * ROWB : 0);
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16>;
+    auto kern = conv3x3_pp_kernel<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, QC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }

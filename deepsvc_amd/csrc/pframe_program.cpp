@@ -11,7 +11,9 @@
 // analysis; the residual decode chain (host range decoder <-> scan kernels, one synchronisation per level) runs on a worker thread and a side
 // stream owned by the program, beside the motion chain and the prediction segment of the caller's stream.
 #include <cstring>
+#include <exception>
 #include <future>
+#include <new>
 #include <memory>
 #include <string>
 #include <vector>
@@ -69,7 +71,10 @@ struct Codec {
 struct dsvc_pframe_program {
     int device = 0, H = 0, W = 0, precision = 0, feature_channels = 0, feature_esize = 0;
     std::vector<void*> tensors;
+    std::vector<uint64_t> tensor_bytes;      // sizes of `tensors`, kept from load time: every relocation / codec reference is checked against them
     void* arena[2] = {nullptr, nullptr};
+    uint64_t arena_bytes[2] = {0, 0};
+    uint64_t slot_bytes[SLOT_N] = {0};       // extents of the frame tensors (caller-owned ones by contract of the call)
     void* owned[SLOT_N] = {nullptr};         // library-owned frame tensors: ref / cur (NHWC fp32), recon / warped / predict (NHWC fp32)
     Program seg[2][6];                       // [variant][E1, E2a, E2, D1, DR, D2]
     Codec codec[2];
@@ -100,10 +105,15 @@ const char* kSegNames[6] = {"E1", "E2a", "E2", "D1", "DR", "D2"};
         if (e_ != hipSuccess) { dsvc_set_error("%s: %s", what, hipGetErrorString(e_)); return DSVC_E_LAUNCH; } \
     } while (0)
 
+// [off, off + len) lies inside [0, total): written so that no sum of blob-controlled 64-bit values can wrap
+inline bool inside(uint64_t off, uint64_t len, uint64_t total) { return off <= total && len <= total - off; }
+
 int load_table(const uint8_t* pay, uint64_t pay_bytes, const BlobTable& bt, HostTable* ht) {
+    // rows / stride are bounded before they are multiplied (a CDF table of compressai has <= 64 .. 320 rows of <= a few thousand entries)
+    DSVC_REQUIRE(bt.rows > 0 && bt.rows <= (1u << 20) && bt.stride > 1 && bt.stride <= (1u << 16), "pframe_program_load: CDF table of %u rows x %u entries", bt.rows, bt.stride);
     const uint64_t n = (uint64_t)bt.rows * bt.stride;
-    DSVC_REQUIRE(bt.rows > 0 && bt.stride > 1 && bt.cdf_off + n * 4 <= pay_bytes && bt.len_off + (uint64_t)bt.rows * 4 <= pay_bytes &&
-                 bt.off_off + (uint64_t)bt.rows * 4 <= pay_bytes, "pframe_program_load: CDF table outside the blob");
+    DSVC_REQUIRE(inside(bt.cdf_off, n * 4, pay_bytes) && inside(bt.len_off, (uint64_t)bt.rows * 4, pay_bytes) &&
+                 inside(bt.off_off, (uint64_t)bt.rows * 4, pay_bytes), "pframe_program_load: CDF table outside the blob");
     ht->cdf.resize(n); ht->len.resize(bt.rows); ht->off.resize(bt.rows); ht->lut.resize((size_t)bt.rows * 256);
     std::memcpy(ht->cdf.data(), pay + bt.cdf_off, n * 4);
     std::memcpy(ht->len.data(), pay + bt.len_off, (size_t)bt.rows * 4);
@@ -117,7 +127,7 @@ int load_table(const uint8_t* pay, uint64_t pay_bytes, const BlobTable& bt, Host
 // copy the ops of one blob program, resolve its relocations against the loaded buffers, keep the caller-slot ones for per-call patching
 int load_program(dsvc_pframe_program* P, const uint8_t* pay, uint64_t pay_bytes, const BlobProgram& bp, Program* out) {
     const uint64_t ob = (uint64_t)bp.n_ops * sizeof(dsvc_scan_op), rb = (uint64_t)bp.n_relocs * sizeof(BlobReloc);
-    DSVC_REQUIRE(bp.ops_off + ob <= pay_bytes && bp.relocs_off + rb <= pay_bytes, "pframe_program_load: program '%.16s' outside the blob", bp.name);
+    DSVC_REQUIRE(inside(bp.ops_off, ob, pay_bytes) && inside(bp.relocs_off, rb, pay_bytes), "pframe_program_load: program '%.16s' outside the blob", bp.name);
     out->ops.resize(bp.n_ops);
     std::memcpy(out->ops.data(), pay + bp.ops_off, ob);
     const BlobReloc* rel = (const BlobReloc*)(pay + bp.relocs_off);
@@ -128,12 +138,16 @@ int load_program(dsvc_pframe_program* P, const uint8_t* pay, uint64_t pay_bytes,
         uint64_t base = 0;
         if (r.kind == KIND_TENSOR) {
             DSVC_REQUIRE(r.index < P->tensors.size(), "pframe_program_load: tensor index %u out of range", r.index);
+            DSVC_REQUIRE(r.delta < P->tensor_bytes[r.index], "pframe_program_load: relocation of '%.16s' points %llu bytes into tensor %u of %llu bytes", bp.name,
+                         (unsigned long long)r.delta, r.index, (unsigned long long)P->tensor_bytes[r.index]);
             base = (uint64_t)(uintptr_t)P->tensors[r.index];
         } else if (r.kind == KIND_ARENA0 || r.kind == KIND_ARENA1) {
             base = (uint64_t)(uintptr_t)P->arena[r.kind - KIND_ARENA0];
             DSVC_REQUIRE(base != 0, "pframe_program_load: '%.16s' uses an arena of size 0", bp.name);
+            DSVC_REQUIRE(r.delta < P->arena_bytes[r.kind - KIND_ARENA0], "pframe_program_load: relocation of '%.16s' outside its arena", bp.name);
         } else if (r.kind == KIND_SLOT) {
             DSVC_REQUIRE(r.index < SLOT_N, "pframe_program_load: frame-tensor slot %u unknown", r.index);
+            DSVC_REQUIRE(r.delta < P->slot_bytes[r.index], "pframe_program_load: relocation of '%.16s' outside frame tensor %u", bp.name, r.index);
             if (P->owned[r.index]) base = (uint64_t)(uintptr_t)P->owned[r.index];
             else { out->caller.push_back(Program::Patch{r.field_off, r.index, r.delta}); continue; }
         } else {
@@ -209,14 +223,16 @@ int decode_codec(Codec& c, hipStream_t st, const uint8_t* y, int64_t ny_bytes, c
 
 }  // namespace
 
-extern "C" int dsvc_pframe_program_load(const void* blob, int64_t nbytes, int32_t device, dsvc_pframe_program** out) {
+static int program_load_impl(const void* blob, int64_t nbytes, int32_t device, dsvc_pframe_program** out) {
     DSVC_REQUIRE(blob && out && nbytes >= (int64_t)sizeof(BlobHead), "pframe_program_load: null / short blob");
     const uint8_t* b = (const uint8_t*)blob;
     BlobHead h;
     std::memcpy(&h, b, sizeof(h));
     DSVC_REQUIRE(std::memcmp(h.magic, "DSVCPRG1", 8) == 0 && h.version == 1, "pframe_program_load: not a DSVC program blob (version 1)");
     DSVC_REQUIRE(h.scan_op_size == sizeof(dsvc_scan_op), "pframe_program_load: blob written for another ABI (op size %u, library %zu)", h.scan_op_size, sizeof(dsvc_scan_op));
-    DSVC_REQUIRE(h.n_codecs == 2 && h.H % 64 == 0 && h.W % 64 == 0 && h.H > 0 && h.W > 0 && h.precision <= 1, "pframe_program_load: bad header");
+    DSVC_REQUIRE(h.n_codecs == 2 && h.H % 64 == 0 && h.W % 64 == 0 && h.H > 0 && h.W > 0 && h.H <= 16384 && h.W <= 16384 && h.precision <= 1 &&
+                 h.feature_channels >= 1 && h.feature_channels <= 4096 && (h.feature_esize == 2 || h.feature_esize == 4) &&
+                 h.n_tensors <= (1u << 20) && h.n_programs <= (1u << 16), "pframe_program_load: bad header");
     const uint64_t tab = sizeof(BlobHead) + (uint64_t)h.n_tensors * sizeof(BlobTensor) + (uint64_t)h.n_programs * sizeof(BlobProgram) + 2 * sizeof(BlobCodec);
     DSVC_REQUIRE(h.payload_off >= tab && h.payload_off <= (uint64_t)nbytes, "pframe_program_load: truncated tables");
     const uint8_t* pay = b + h.payload_off;
@@ -230,33 +246,52 @@ extern "C" int dsvc_pframe_program_load(const void* blob, int64_t nbytes, int32_
     P->device = device; P->H = (int)h.H; P->W = (int)h.W; P->precision = (int)h.precision;
     P->feature_channels = (int)h.feature_channels; P->feature_esize = (int)h.feature_esize;
     P->tensors.assign(h.n_tensors, nullptr);
+    P->tensor_bytes.assign(h.n_tensors, 0);
     for (uint32_t i = 0; i < h.n_tensors; ++i) {
         BlobTensor t; std::memcpy(&t, &bt[i], sizeof(t));
         DSVC_REQUIRE(t.nbytes > 0 && t.nbytes < (1ull << 36), "pframe_program_load: tensor %u of %llu bytes", i, (unsigned long long)t.nbytes);
         HIP_OK(hipMalloc(&P->tensors[i], t.nbytes), "pframe_program_load: hipMalloc");
+        P->tensor_bytes[i] = t.nbytes;
         if (t.data_off < 0) { HIP_OK(hipMemset(P->tensors[i], 0, t.nbytes), "pframe_program_load: hipMemset"); }
         else {
-            DSVC_REQUIRE((uint64_t)t.data_off + t.nbytes <= pay_bytes, "pframe_program_load: tensor %u outside the blob", i);
+            DSVC_REQUIRE(inside((uint64_t)t.data_off, t.nbytes, pay_bytes), "pframe_program_load: tensor %u outside the blob", i);
             HIP_OK(hipMemcpy(P->tensors[i], pay + t.data_off, t.nbytes, hipMemcpyHostToDevice), "pframe_program_load: upload");
         }
     }
     for (int k = 0; k < 2; ++k)
-        if (h.arena[k]) HIP_OK(hipMalloc(&P->arena[k], h.arena[k]), "pframe_program_load: hipMalloc (arena)");
+        if (h.arena[k]) {
+            DSVC_REQUIRE(h.arena[k] < (1ull << 38), "pframe_program_load: arena %d of %llu bytes", k, (unsigned long long)h.arena[k]);
+            HIP_OK(hipMalloc(&P->arena[k], h.arena[k]), "pframe_program_load: hipMalloc (arena)");
+            P->arena_bytes[k] = h.arena[k];
+        }
     const size_t frame3 = (size_t)h.H * h.W * 3 * 4;
-    for (int s : {SLOT_REF, SLOT_CUR, SLOT_RECON, SLOT_WARPED, SLOT_PREDICT}) HIP_OK(hipMalloc(&P->owned[s], frame3), "pframe_program_load: hipMalloc (frame)");
+    for (int s : {SLOT_REF, SLOT_CUR, SLOT_RECON, SLOT_WARPED, SLOT_PREDICT}) {
+        HIP_OK(hipMalloc(&P->owned[s], frame3), "pframe_program_load: hipMalloc (frame)");
+        P->slot_bytes[s] = frame3;
+    }
+    // caller-owned frame tensors (include/dsvc.h): sm_fea float32 [1,256,H/4,W/4], the carried feature [1,C,H,W] in the storage type
+    P->slot_bytes[SLOT_SM_FEA] = (uint64_t)256 * (h.H / 4) * (h.W / 4) * 4;
+    P->slot_bytes[SLOT_FEATURE_IN] = P->slot_bytes[SLOT_FEATURE_OUT] = (uint64_t)h.H * h.W * h.feature_channels * h.feature_esize;
 
     for (int ci = 0; ci < 2; ++ci) {
         BlobCodec c; std::memcpy(&c, &bc[ci], sizeof(c));
         Codec& C = P->codec[ci];
-        DSVC_REQUIRE(c.ngroups >= 1 && c.ngroups <= 8 && c.M > 0 && c.Nz > 0 && c.d > 0 && c.M % c.d == 0, "pframe_program_load: codec %d geometry", ci);
+        DSVC_REQUIRE(c.ngroups >= 1 && c.ngroups <= 8 && c.M > 0 && c.M <= 4096 && c.Nz > 0 && c.Nz <= 4096 && c.d > 0 && c.M % c.d == 0 &&
+                     c.zh > 0 && c.zw > 0 && c.yh > 0 && c.yw > 0 && c.zh <= 4096 && c.zw <= 4096 && c.yh <= 4096 && c.yw <= 4096, "pframe_program_load: codec %d geometry", ci);
         C.M = c.M; C.Nz = c.Nz; C.zh = c.zh; C.zw = c.zw; C.d = c.d; C.yh = c.yh; C.yw = c.yw;
         C.nz = (int64_t)c.Nz * c.zh * c.zw; C.ny = (int64_t)c.M * c.yh * c.yw; C.ns = (int64_t)c.d * c.yh * c.yw;
         int gmax = 0, gsum = 0;
+        for (uint32_t g = 0; g < c.ngroups; ++g) DSVC_REQUIRE(c.groups[g] >= 1 && c.groups[g] <= 64, "pframe_program_load: codec %d slice group of %u slices", ci, c.groups[g]);
         for (uint32_t g = 0; g < c.ngroups; ++g) { C.groups.push_back((int)c.groups[g]); gmax = std::max(gmax, (int)c.groups[g]); gsum += (int)c.groups[g]; }
         DSVC_REQUIRE(gsum * c.d == c.M, "pframe_program_load: codec %d slice groups do not cover the latent", ci);
         int32_t** dst[4] = {&C.staging, &C.z_sym, &C.idx_dev, &C.sym_dev};
+        // what the staging copies of compress / decompress read and write behind each reference (stage_out, decode_codec), in int32 elements
+        const uint64_t need[4] = {(uint64_t)(C.nz + 2 * C.ny), (uint64_t)C.nz, (uint64_t)gmax * (uint64_t)C.ns, (uint64_t)gmax * (uint64_t)C.ns};
         for (int r = 0; r < 4; ++r) {
             DSVC_REQUIRE(c.refs[r].kind == KIND_TENSOR && c.refs[r].index < h.n_tensors, "pframe_program_load: codec %d buffer reference", ci);
+            DSVC_REQUIRE(inside(c.refs[r].delta, need[r] * 4, P->tensor_bytes[c.refs[r].index]),
+                         "pframe_program_load: codec %d buffer %d (%llu bytes at +%llu) does not fit tensor %u of %llu bytes", ci, r, (unsigned long long)(need[r] * 4),
+                         (unsigned long long)c.refs[r].delta, c.refs[r].index, (unsigned long long)P->tensor_bytes[c.refs[r].index]);
             *dst[r] = (int32_t*)((char*)P->tensors[c.refs[r].index] + c.refs[r].delta);
         }
         if (int rc = load_table(pay, pay_bytes, c.tables[0], &C.eb)) return rc;
@@ -308,8 +343,8 @@ extern "C" int dsvc_pframe_program_info(const dsvc_pframe_program* p, dsvc_pfram
     return DSVC_OK;
 }
 
-extern "C" int dsvc_pframe_compress(dsvc_pframe_program* P, void* stream, const float* ref, const float* cur, const float* sm_fea, const void* feature,
-                                    uint8_t* const out[4], const int64_t cap[4], int64_t nbytes[4]) {
+static int compress_impl(dsvc_pframe_program* P, void* stream, const float* ref, const float* cur, const float* sm_fea, const void* feature,
+                         uint8_t* const out[4], const int64_t cap[4], int64_t nbytes[4]) {
     DSVC_REQUIRE(P && ref && cur && sm_fea && out && cap && nbytes, "pframe_compress: null argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(hipSetDevice(P->device), "pframe_compress: hipSetDevice");
@@ -337,8 +372,8 @@ extern "C" int dsvc_pframe_compress(dsvc_pframe_program* P, void* stream, const 
     return rc;
 }
 
-extern "C" int dsvc_pframe_decompress(dsvc_pframe_program* P, void* stream, const float* ref, const uint8_t* const strings[4], const int64_t nbytes[4],
-                                      const float* sm_fea, const void* feature, void* feature_out, float* recon, float* warped, float* predict) {
+static int decompress_impl(dsvc_pframe_program* P, void* stream, const float* ref, const uint8_t* const strings[4], const int64_t nbytes[4],
+                           const float* sm_fea, const void* feature, void* feature_out, float* recon, float* warped, float* predict) {
     DSVC_REQUIRE(P && ref && strings && nbytes && sm_fea && feature_out && recon, "pframe_decompress: null argument");
     for (int i = 0; i < 4; ++i) DSVC_REQUIRE(strings[i] != nullptr && nbytes[i] >= 8, "pframe_decompress: string %d missing", i);
     hipStream_t st = (hipStream_t)stream;
@@ -375,4 +410,25 @@ extern "C" int dsvc_pframe_decompress(dsvc_pframe_program* P, void* stream, cons
         if (o.dst)
             if (int rc = dsvc_nhwc_to_nchw(stream, P->owned[o.slot], 3, DSVC_F32, o.dst, 1, 3, P->H, P->W)) return rc;
     return DSVC_OK;
+}
+
+// ---- the exported entry points: no C++ exception leaves the library ------------------------------------------------------------
+// std::async can throw std::system_error, the vectors sized from blob fields std::bad_alloc / std::length_error: a C, Go or Rust host
+// would see std::terminate.  Every entry point turns them into a status + dsvc_last_error() text.
+#define DSVC_NOEXCEPT_CALL(where_, expr)                                                       \
+    try { return (expr); }                                                                   \
+    catch (const std::bad_alloc&) { dsvc_set_error("%s: out of host memory", where_); return DSVC_E_ARG; }       \
+    catch (const std::exception& e) { dsvc_set_error("%s: %s", where_, e.what()); return DSVC_E_LAUNCH; }        \
+    catch (...) { dsvc_set_error("%s: unknown C++ exception", where_); return DSVC_E_LAUNCH; }
+
+extern "C" int dsvc_pframe_program_load(const void* blob, int64_t nbytes, int32_t device, dsvc_pframe_program** out) {
+    DSVC_NOEXCEPT_CALL("pframe_program_load", program_load_impl(blob, nbytes, device, out))
+}
+extern "C" int dsvc_pframe_compress(dsvc_pframe_program* P, void* stream, const float* ref, const float* cur, const float* sm_fea, const void* feature,
+                                    uint8_t* const out[4], const int64_t cap[4], int64_t nbytes[4]) {
+    DSVC_NOEXCEPT_CALL("pframe_compress", compress_impl(P, stream, ref, cur, sm_fea, feature, out, cap, nbytes))
+}
+extern "C" int dsvc_pframe_decompress(dsvc_pframe_program* P, void* stream, const float* ref, const uint8_t* const strings[4], const int64_t nbytes[4],
+                                      const float* sm_fea, const void* feature, void* feature_out, float* recon, float* warped, float* predict) {
+    DSVC_NOEXCEPT_CALL("pframe_decompress", decompress_impl(P, stream, ref, strings, nbytes, sm_fea, feature, feature_out, recon, warped, predict))
 }

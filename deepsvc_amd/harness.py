@@ -133,7 +133,13 @@ def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None, overla
     for ln in range(L):                      # one lane at a time, each to completion (DeepSVC.warm_up: deterministic, no cross-lane retries)
         if not mine[ln]:
             continue
-        frames, sms = gops[mine[ln][0]]
+        # warm up on the lane's first GOP that HAS P-frames (a lone key frame -- e.g. the tail GOP of a sequence -- has nothing to code);
+        # a lane that holds only such GOPs borrows the P-frames of any other GOP: the recordings depend on the shape, not on the content
+        own = [u for u in mine[ln] if len(gops[u][0]) >= 2]
+        anyone = own or [u for u in range(len(gops)) if len(gops[u][0]) >= 2]
+        if not anyone:
+            continue                         # nothing but key frames anywhere: no P-frame will be coded, nothing to warm up
+        frames, sms = gops[anyone[0]]
         with torch.cuda.stream(streams[ln]):
             ref = pad(frames[0], 64)
             if i_models is not None:

@@ -443,8 +443,8 @@ class ChannelSplitICIP2020ResB(nn.Module):
             ps = self.__dict__["_fp_params"] = [p for p in self.parameters()]
         # (+ the table generations of the two entropy models: a direct gaussian_conditional.update_scale_table() / entropy_bottleneck.update()
         #  replaces the device-side tables the recordings point to without touching a parameter)
-        return sum(p._version for p in ps) + (id(ps[0]) if ps else 0) + \
-            (self.entropy_bottleneck._table_gen << 20) + (self.gaussian_conditional._table_gen << 40)
+        # a tuple, not an arithmetic mix: _TABLE_GEN is process-wide and unbounded, shifted sums would alias once a generation passes 2^20
+        return (sum(p._version for p in ps), id(ps[0]) if ps else 0, self.entropy_bottleneck._table_gen, self.gaussian_conditional._table_gen)
 
     def _plan(self, B, h, w, device):
         key = (B, h, w, str(device), ops.RT.mode)

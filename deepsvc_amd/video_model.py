@@ -94,6 +94,8 @@ class DeepSVC(nn.Module):
         segment of both codecs has its HIP graph and the frame segments of both variants have been replayed once.  Everything a
         recording depends on belongs to this instance (per-codec packing epoch, per-model program cache), so other instances (GOP lanes)
         warming up before or after do not invalidate it.  -> number of frames coded; raises if the model is not ready after max_frames."""
+        if len(frames) == 0 or len(sm_feas) == 0:
+            raise ValueError("DeepSVC.warm_up: needs at least one P-frame and one semantic feature to code (got a lone key frame?)")
         ref, feat = ref_frame, None
         first = ops.to_act(ref_frame)
         B, H, W = first.B, first.H, first.W

@@ -203,6 +203,32 @@ def test_c_frame_api_refuses_malformed_blobs(tmp_path):
     bad = bytearray(blob)
     struct.pack_into("<II", bad, codec0 + 64, 9, 1 << 30)                  # refs[0] = {kind 9, tensor index 2^30}
     refused(bad, "codec buffer reference")
+    # 64-bit offsets that WRAP when a length is added to them: `off + len <= size` passes for off near 2^64;
+    # the loader must compare `len <= size - off` instead, and bound rows / stride before multiplying them
+    U64 = (1 << 64) - 1
+    prog0 = 72 + 16 * n_tensors                                             # BlobProgram: char[16], 4 x uint32, ops_off, relocs_off
+    for name, at, fmt, val in [("ops_off near 2^64", prog0 + 32, "<Q", U64 - 15), ("relocs_off near 2^64", prog0 + 40, "<Q", U64 - 7),
+                               ("tables[0].cdf_off near 2^64", codec0 + 128 + 8, "<Q", U64 - 3), ("tables[0].len_off near 2^64", codec0 + 128 + 16, "<Q", U64 - 3),
+                               ("tables[1].off_off near 2^64", codec0 + 160 + 24, "<Q", U64), ("refs[0].delta near 2^64", codec0 + 64 + 8, "<Q", U64 - 63),
+                               ("refs[2].delta beyond its tensor", codec0 + 64 + 2 * 16 + 8, "<Q", 1 << 33)]:
+        bad = bytearray(blob)
+        struct.pack_into(fmt, bad, at, val)
+        refused(bad, name)
+    bad = bytearray(blob)
+    struct.pack_into("<II", bad, codec0 + 128, 1 << 31, 1 << 31)           # rows * stride * 4 = 2^64: wraps to 0
+    refused(bad, "CDF table whose rows x stride x 4 wraps")
+    bad = bytearray(blob)
+    struct.pack_into("<II", bad, codec0 + 128, (1 << 32) - 1, 2)
+    refused(bad, "CDF table with 2^32 - 1 rows")
+    bad = bytearray(blob)
+    struct.pack_into("<4I", bad, codec0 + 8, 1 << 30, 1 << 30, 8, 1 << 30)  # zh, zw, d, yh: products overflow int64 sizes
+    refused(bad, "codec geometry beyond any picture")
+    bad = bytearray(blob)
+    nrel = struct.unpack_from("<I", blob, prog0 + 24)[0]
+    rel0 = payload_off + struct.unpack_from("<Q", blob, prog0 + 40)[0]      # first relocation of the first program: {field_off, kind, index, pad, delta}
+    assert nrel > 0
+    struct.pack_into("<Q", bad, rel0 + 16, U64 - 8)
+    refused(bad, "relocation delta near 2^64")
     rc, h, msg = load(blob)
     assert rc == 0 and h.value, f"the intact blob no longer loads: {msg}"
     L.dsvc_pframe_program_destroy(h)

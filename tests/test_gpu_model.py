@@ -312,6 +312,33 @@ def test_gop_lanes_match_sequential_coding():
         ops.set_precision("fp32")
 
 
+def test_gop_lanes_with_a_lone_key_frame_gop():
+    """a lane whose FIRST unit is a lone key frame (the tail GOP of a sequence: nothing to code) used to reach
+    DeepSVC.warm_up with an empty frame list (ZeroDivisionError).  The harness now warms such a lane on another GOP's P-frames, and
+    warm_up itself refuses an empty list with a clear ValueError.  Lane 1 below holds only the lone key frame."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("f16")
+    try:
+        size = 128
+        fr = [f.to(DEV) for f in synth.make_frames(size, size, 3, seed=7)]
+        sms = [None] + [synth.make_sm_fea(size, size, t, seed=7).to(DEV) for t in (1, 2)]
+        gops = [(fr, sms), ([fr[0]], [None])]                 # unit 0: key + 2 P-frames (lane 0); unit 1: a lone key frame (lane 1)
+        models = []
+        for _ in range(2):
+            m = synth.make_model("W0"); m.update(force=True); models.append(m.to(DEV))
+        seq = harness.code_gop(models[0], fr, sms, unit=0, sync=torch.cuda.synchronize)
+        par = harness.code_gops_in_lanes(models, gops, torch.device(DEV))
+        assert len(par) == len(seq) == 2
+        for a, b in zip(seq, par):
+            assert a[:7] == b[:7], (a[:7], b[:7])
+        with pytest.raises(ValueError, match="at least one P-frame"):
+            models[0].warm_up(fr[0], [], [])
+        # nothing but key frames anywhere: no P-frame to code, no warm-up, no rows
+        assert harness.code_gops_in_lanes(models, [([fr[0]], [None])], torch.device(DEV)) == []
+    finally:
+        ops.set_precision("fp32")
+
+
 def test_weight_edit_invalidates_recorded_scan():
     """recorded scan programs / HIP graphs hold pointers to PACKED copies of the weights and never pass through
     Conv2d._packed on replay.  After an in-place weight edit (or load_state_dict) on a warmed model, a decompress-only call must

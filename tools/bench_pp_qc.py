@@ -1,0 +1,59 @@
+"""A/B of the two-group 3x3 kernel's quad-contiguous epilogue (option pp_qc, csrc/conv3x3_pp.hip) at 1088x1920, f16: every epilogue variant
+with the option off / on in the same process, interleaved over three rounds, under the default MFMA-shape policy (pp16 = 1) and with the
+32x32x16 shape forced (pp16 = 0); outputs compared bit for bit.
+    python tools/bench_pp_qc.py [--rounds 3] [--iters 15]"""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepsvc_amd import _native as N, ops  # noqa: E402
+from deepsvc_amd.modules import Conv2d  # noqa: E402
+
+ap = argparse.ArgumentParser(); ap.add_argument("--rounds", type=int, default=3); ap.add_argument("--iters", type=int, default=15)
+args = ap.parse_args()
+ops.set_precision("f16")
+dev, h = "cuda:0", torch.float16
+H, W = 1088, 1920
+torch.manual_seed(0)
+x = ops.Act((torch.randn((1, H, W, 64), device=dev)).to(h))
+r1 = ops.Act(torch.randn((1, H, W, 64), device=dev).to(h))
+r2 = ops.Act(torch.randn((1, H, W, 64), device=dev).to(h))
+conv = Conv2d(64, 64, 3, 1, 1).to(dev)
+c32 = Conv2d(64, 32, 3, 1, 1).to(dev)
+c1 = Conv2d(32, 64, 3, 1, 1).to(dev)
+x32 = ops.Act(torch.randn((1, H, W, 32), device=dev).to(h))
+post = Conv2d(64, 64, 1, 1, 0).to(dev)._packed([64], dev)
+CASES = [("plain", conv, x, {}), ("pre relu + act relu", conv, x, dict(pre_act=N.ACT_RELU, act=N.ACT_RELU, slope=0.0)),
+         ("pre lrelu + act lrelu", conv, x, dict(pre_act=N.ACT_LRELU, act=N.ACT_LRELU, slope=0.01)),
+         ("res1", conv, x, dict(res1=r1)), ("res1 + res2", conv, x, dict(res1=r1, res2=r2)), ("act + res1 + post(1x1)", conv, x, dict(act=N.ACT_LRELU, res1=r1, post=post)),
+         ("64->32", c32, x, {}), ("32->64 (1 chunk)", c1, x32, dict(act=N.ACT_LRELU))]
+best = {}
+ref = {}
+for rnd in range(args.rounds):
+    for name, m, inp, kw in CASES:
+        for shape in (1, 0):
+            for qc in (0, 1):
+                ops.set_option("pp16", shape); ops.set_option("pp_qc", qc)
+                out = ops.new_act(1, H, W, m.out_channels, h, dev)
+                for _ in range(2):
+                    m.run(inp, out, out_dtype=h, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(args.iters):
+                    m.run(inp, out, out_dtype=h, **kw)
+                e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / args.iters * 1e3
+                key = (name, shape, qc)
+                best[key] = min(best.get(key, 1e9), us)
+                if rnd == 0:
+                    if qc == 0:
+                        ref[(name, shape)] = out.buf.clone()
+                    else:
+                        same = torch.equal(ref[(name, shape)].view(torch.int16), out.buf.view(torch.int16))
+                        print(f"   {name:28s} pp16={shape}: outputs bit-identical with pp_qc: {same}", flush=True)
+                print(f"round {rnd} {name:28s} pp16={shape} pp_qc={qc} {us:7.1f} us", flush=True)
+print("\nbest of rounds (us):  variant | pp16=1 qc0 -> qc1 | pp16=0 qc0 -> qc1 | bytes moved at the best")
+for name, m, inp, kw in CASES:
+    nb = (inp.C + m.out_channels * (1 + ("res1" in kw) + ("res2" in kw))) * H * W * 2
+    b = min(best[(name, s, q)] for s in (0, 1) for q in (0, 1))
+    print(f"{name:28s} | {best[(name, 1, 0)]:6.1f} -> {best[(name, 1, 1)]:6.1f} | {best[(name, 0, 0)]:6.1f} -> {best[(name, 0, 1)]:6.1f} | {nb / b / 1e6:5.2f} TB/s", flush=True)
+ops.set_option("pp16", 1); ops.set_option("pp_qc", 1)
