@@ -121,6 +121,29 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
     return make_uint4(u[0], u[1], u[2], u[3]);
 }
 
+// RMIX (round 5): the residual add and the f16 packing of the epilogue as mixed-precision FMAs.  f16(x + r) for an fp32 x and a packed f16
+// residual r took two v_cvt_f32_f16, two v_add_f32 and one v_cvt_pk_f16_f32 per output dword; v_fma_mixlo_f16 / v_fma_mixhi_f16 compute
+// r.half * 1.0 + x in fp32 and round ONCE to the f16 half of the destination: two instructions per dword.  An E-phase instruction costs
+// 15-25 clocks of issue beside the partner group's prioritised MFMA stream (in-kernel stamps), so the 96 instructions saved per
+// tile and wave are the difference between E ~ 4800 and E ~ M.  Numerically the sum is now rounded once (fp32 sum -> f16) instead of twice
+// (fp32 add, then f16): results can differ from the two-step form in the last f16 bit where the fp32-rounded sum sat exactly on an f16 tie.
+__device__ __forceinline__ unsigned mix_pack_add(unsigned r, float x0, float x1) {      // {f16(r.lo + x0), f16(r.hi + x1)}
+    unsigned t = 0;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(t) : "v"(r), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(r), "v"(x1));
+    return t;
+}
+__device__ __forceinline__ float mix_add_lo(unsigned r, float x) {      // fp32(r.lo + x): the same bits as x + float(r.lo)
+    float t;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(r), "v"(x));
+    return t;
+}
+__device__ __forceinline__ float mix_add_hi(unsigned r, float x) {
+    float t;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t) : "v"(r), "v"(x));
+    return t;
+}
+
 // NCH: 32-channel input chunks (2: the schedule above; 1: inputs of <= 32 channels, phases M0 | E+S0 only).
 // HEAD: narrow output head (Cout <= 8, any activation, fp32 or f16 out, optional residual of either type): one N-tile
 // is computed and the lanes that hold channels 0..7 store them element-wise.
@@ -151,7 +174,7 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
 // With QC the packed vectors change lanes once more on their way out -- lane 4*pixel + piece, one ds_permute_b32 per dword: the LDS
 // crossbar, no LDS memory -- so that a quad writes 64 contiguous bytes; residual vectors are loaded in that layout and pulled back with
 // ds_bpermute_b32.  Pure data movement: results are bit-identical to QC = false (tests/test_gpu_ops.py).
-template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false, bool QC = false>
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false, bool QC = false, bool RMIX = false>
 __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kernel(const ConvParams p, int ntiles, int iters, float act_slope,
                                                               float pre_slope) {
     DSVC_F16_SAT();
@@ -553,6 +576,16 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
         if constexpr (ACT && !POST) {                                                                               \
             _Pragma("unroll") for (int v = 0; v < 4; ++v) { lo[v] = lrelu_f(lo[v], act_slope); hi[v] = lrelu_f(hi[v], act_slope); } \
         }                                                                                                           \
+        if constexpr (HAS_R1 && RMIX) {                                                                             \
+            uint4 ra = from_qc(res[PB * NT + G]);                                                                   \
+            if constexpr (HAS_R2) {      /* (x + r1) in fp32 -- the bits of the two-step form --, then f16(. + r2) */  \
+                lo[0] = mix_add_lo(ra.x, lo[0]); lo[1] = mix_add_hi(ra.x, lo[1]); lo[2] = mix_add_lo(ra.y, lo[2]); lo[3] = mix_add_hi(ra.y, lo[3]); \
+                hi[0] = mix_add_lo(ra.z, hi[0]); hi[1] = mix_add_hi(ra.z, hi[1]); hi[2] = mix_add_lo(ra.w, hi[2]); hi[3] = mix_add_hi(ra.w, hi[3]); \
+                ra = from_qc(buf_load16(rr2, o_r216[PB] + 64 * G));                                                 \
+            }                                                                                                       \
+            buf_store16(rout, o_out16[PB] + 64 * G, to_qc(make_uint4(mix_pack_add(ra.x, lo[0], lo[1]), mix_pack_add(ra.y, lo[2], lo[3]),   \
+                                                                     mix_pack_add(ra.z, hi[0], hi[1]), mix_pack_add(ra.w, hi[2], hi[3]))));  \
+        } else {                                                                                                    \
         if constexpr (HAS_R1) {                                                                                     \
             const uint4 ra = from_qc(res[PB * NT + G]);                                                             \
             lo[0] += h16_lo(ra.x); lo[1] += h16_hi(ra.x); lo[2] += h16_lo(ra.y); lo[3] += h16_hi(ra.y);             \
@@ -564,6 +597,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
             }                                                                                                       \
         }                                                                                                           \
         buf_store16(rout, o_out16[PB] + 64 * G, to_qc(make_uint4(pk_h16(lo[0], lo[1]), pk_h16(lo[2], lo[3]), pk_h16(hi[0], hi[1]), pk_h16(hi[2], hi[3])))); \
+        }                                                                                                           \
     }
             PP16_OUT(0, 0) PP16_OUT(0, 1) PP16_OUT(1, 0) PP16_OUT(1, 1) PP16_OUT(2, 0) PP16_OUT(2, 1) PP16_OUT(3, 0) PP16_OUT(3, 1)
 #undef PP16_OUT
@@ -599,6 +633,26 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
         if constexpr (ACT && !POST) {                                                                               \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) { v0[j] = lrelu_f(v0[j], act_slope); v1[j] = lrelu_f(v1[j], act_slope); } \
         }                                                                                                           \
+        unsigned p0[4], p1[4];       /* the packed results in the compute layout */                                 \
+        if constexpr (HAS_R1 && RMIX) {                                                                             \
+            const uint4 ra = from_qc(res[(M * NT + N) * 2]), rb = from_qc(res[(M * NT + N) * 2 + 1]);               \
+            const unsigned ma[4] = {ra.x, ra.y, ra.z, ra.w}, mb[4] = {rb.x, rb.y, rb.z, rb.w};                      \
+            unsigned xa[4], xb[4];                                                                                  \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(ma[d], mb[d], xa[d], xb[d])                        \
+            if constexpr (HAS_R2) {      /* (x + r1) in fp32 -- the bits of the two-step form --, then f16(. + r2) */  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+                    v0[2 * j] = mix_add_lo(xa[j], v0[2 * j]); v0[2 * j + 1] = mix_add_hi(xa[j], v0[2 * j + 1]);     \
+                    v1[2 * j] = mix_add_lo(xb[j], v1[2 * j]); v1[2 * j + 1] = mix_add_hi(xb[j], v1[2 * j + 1]);     \
+                }                                                                                                   \
+                const uint4 ca = from_qc(buf_load16(rr2, o_r2[M][0] + 64 * N)), cb = from_qc(buf_load16(rr2, o_r2[M][1] + 64 * N));   \
+                const unsigned na[4] = {ca.x, ca.y, ca.z, ca.w}, nb[4] = {cb.x, cb.y, cb.z, cb.w};                  \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(na[d], nb[d], xa[d], xb[d])                    \
+            }                                                                                                       \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                         \
+                p0[d] = mix_pack_add(xa[d], v0[2 * d], v0[2 * d + 1]);                                              \
+                p1[d] = mix_pack_add(xb[d], v1[2 * d], v1[2 * d + 1]);                                              \
+            }                                                                                                       \
+        } else {                                                                                                    \
         if constexpr (HAS_R1) {                                                                                     \
             const uint4 ra = from_qc(res[(M * NT + N) * 2]), rb = from_qc(res[(M * NT + N) * 2 + 1]);               \
             const unsigned ma[4] = {ra.x, ra.y, ra.z, ra.w}, mb[4] = {rb.x, rb.y, rb.z, rb.w};                      \
@@ -619,9 +673,11 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
                 }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d) { p0[d] = pk_h16(v0[2 * d], v0[2 * d + 1]); p1[d] = pk_h16(v1[2 * d], v1[2 * d + 1]); } \
+        }                                                                                                           \
         unsigned s0[4], s1[4];                                                                                      \
         _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                               \
-            SWAP16(pk_h16(v0[2 * d], v0[2 * d + 1]), pk_h16(v1[2 * d], v1[2 * d + 1]), s0[d], s1[d])             \
+            SWAP16(p0[d], p1[d], s0[d], s1[d])                                                                      \
         buf_store16(rout, o_out[M][0] + 64 * N, to_qc(make_uint4(s0[0], s0[1], s0[2], s0[3])));                     \
         buf_store16(rout, o_out[M][1] + 64 * N, to_qc(make_uint4(s1[0], s1[1], s1[2], s1[3])));                     \
     }
@@ -686,10 +742,15 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     if (!g) lds_barrier();               // matches group 1's leading barrier
 }
 
-template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false, bool QC = false>
+template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false, bool QC = false, bool RMIX = false>
 int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, float pre_slope) {
+#ifdef DSVC_PP_QC_VARIANT                       // measured slower (profiles/r05_pp_epilogue_experiments.txt): only in the variant build of tools/bench_pp_qc.py
     if constexpr (!QC && !HEAD) {               // option "pp_qc": quad-contiguous epilogue (see the kernel's header comment)
-        if (g_dsvc_opt.pp_qc) return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, true>(st, p, ntiles, act_slope, pre_slope);
+        if (g_dsvc_opt.pp_qc) return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, true, RMIX>(st, p, ntiles, act_slope, pre_slope);
+    }
+#endif
+    if constexpr (!RMIX && !HEAD && HAS_R1) {   // option "pp_mix": residual add + f16 packing as mixed-precision FMAs
+        if (g_dsvc_opt.pp_mix) return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, QC, true>(st, p, ntiles, act_slope, pre_slope);
     }
     if constexpr (!M16 && !HEAD) {
         // option "pp16": 0 = 32x32x16 everywhere, 2 = 16x16x32 everywhere but the narrow heads, 1 (default) = where it measured faster
@@ -697,12 +758,12 @@ int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, 
         // 212 -> 202 us; slower or equal elsewhere (plain 152 -> 153, pre + act 165 -> 174, two residuals 235 -> 254, 64 -> 32 99 -> 103)
         const bool faster16 = NCH == 2 && NT == 2 && !PRE && HAS_R1 && !HAS_R2;
         if (g_dsvc_opt.pp16 == 2 || (g_dsvc_opt.pp16 == 1 && faster16))
-            return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, true, QC>(st, p, ntiles, act_slope, pre_slope);
+            return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, true, QC, RMIX>(st, p, ntiles, act_slope, pre_slope);
     }
     const size_t lds = (size_t)NCH * 9 * NT * 32 * ROWB + (size_t)2 * PP_NPATCH * ROWB + (size_t)2 * NT * 32 * sizeof(float) +
                        (POST ? (size_t)NT * NT * 32 * ROWB : 0);
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, QC>;
+    auto kern = conv3x3_pp_kernel<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, QC, RMIX>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }

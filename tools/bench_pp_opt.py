@@ -1,14 +1,17 @@
-"""A/B of the two-group 3x3 kernel's quad-contiguous epilogue (option pp_qc, csrc/conv3x3_pp.hip) at 1088x1920, f16: every epilogue variant
-with the option off / on in the same process, interleaved over three rounds, under the default MFMA-shape policy (pp16 = 1) and with the
-32x32x16 shape forced (pp16 = 0); outputs compared bit for bit.
-    python tools/bench_pp_qc.py [--rounds 3] [--iters 15]"""
+"""A/B of an epilogue option of the two-group 3x3 kernel (csrc/conv3x3_pp.hip) at 1088x1920, f16: every epilogue variant with the option
+off / on in the same process, interleaved over the rounds, under the default MFMA-shape policy (pp16 = 1) and with the 32x32x16 shape
+forced (pp16 = 0); outputs compared bit for bit.
+    python tools/bench_pp_opt.py --opt pp_mix [--rounds 3] [--iters 15]
+    pp_mix: residual add + f16 packing as mixed-precision FMAs (default on)
+    pp_qc:  quad-contiguous stores / residual loads through ds_permute (needs a library built with -DDSVC_PP_QC_VARIANT:
+            python -c "from deepsvc_amd import build; build.build(variant='qc', defines=['-DDSVC_PP_QC_VARIANT'])", DSVC_LIB=deepsvc_amd/lib/libdsvc_qc.so)"""
 import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepsvc_amd import _native as N, ops  # noqa: E402
 from deepsvc_amd.modules import Conv2d  # noqa: E402
 
-ap = argparse.ArgumentParser(); ap.add_argument("--rounds", type=int, default=3); ap.add_argument("--iters", type=int, default=15)
+ap = argparse.ArgumentParser(); ap.add_argument("--rounds", type=int, default=3); ap.add_argument("--iters", type=int, default=15); ap.add_argument("--opt", default="pp_mix")
 args = ap.parse_args()
 ops.set_precision("f16")
 dev, h = "cuda:0", torch.float16
@@ -32,7 +35,7 @@ for rnd in range(args.rounds):
     for name, m, inp, kw in CASES:
         for shape in (1, 0):
             for qc in (0, 1):
-                ops.set_option("pp16", shape); ops.set_option("pp_qc", qc)
+                ops.set_option("pp16", shape); ops.set_option(args.opt, qc)
                 out = ops.new_act(1, H, W, m.out_channels, h, dev)
                 for _ in range(2):
                     m.run(inp, out, out_dtype=h, **kw)
@@ -49,11 +52,11 @@ for rnd in range(args.rounds):
                         ref[(name, shape)] = out.buf.clone()
                     else:
                         same = torch.equal(ref[(name, shape)].view(torch.int16), out.buf.view(torch.int16))
-                        print(f"   {name:28s} pp16={shape}: outputs bit-identical with pp_qc: {same}", flush=True)
-                print(f"round {rnd} {name:28s} pp16={shape} pp_qc={qc} {us:7.1f} us", flush=True)
+                        print(f"   {name:28s} pp16={shape}: outputs bit-identical with {args.opt}: {same}", flush=True)
+                print(f"round {rnd} {name:28s} pp16={shape} {args.opt}={qc} {us:7.1f} us", flush=True)
 print("\nbest of rounds (us):  variant | pp16=1 qc0 -> qc1 | pp16=0 qc0 -> qc1 | bytes moved at the best")
 for name, m, inp, kw in CASES:
     nb = (inp.C + m.out_channels * (1 + ("res1" in kw) + ("res2" in kw))) * H * W * 2
     b = min(best[(name, s, q)] for s in (0, 1) for q in (0, 1))
     print(f"{name:28s} | {best[(name, 1, 0)]:6.1f} -> {best[(name, 1, 1)]:6.1f} | {best[(name, 0, 0)]:6.1f} -> {best[(name, 0, 1)]:6.1f} | {nb / b / 1e6:5.2f} TB/s", flush=True)
-ops.set_option("pp16", 1); ops.set_option("pp_qc", 1)
+ops.set_option("pp16", 1); ops.set_option(args.opt, 0 if args.opt == "pp_qc" else 1)
