@@ -53,6 +53,33 @@ def _resource_usage(remarks):
     return out
 
 
+_OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+_WIDE_STORE_SOFF = re.compile(r"\b(buffer|tbuffer)_store_(dwordx[34]|format_xyzw?)\s+v\[\d+:\d+\],\s*(?:v\d+|v\[\d+:\d+\]|off),\s*s\[\d+:\d+\],\s*(s\d+|m0|vcc_lo|vcc_hi|ttmp\d+)\b")
+
+
+def wide_stores_with_register_soffset(obj):
+    """Disassembles the gfx950 code object inside a compiled .hip object and returns the wide buffer stores (more than 64 bits of data) whose
+    scalar offset operand is a REGISTER.  On gfx950 with ROCm 7.2 such a store may be followed directly by a vector instruction that overwrites
+    its data registers (the compiler inserts the wait state only for stores WITHOUT a register offset), and under memory load the store then
+    writes the new register contents: the two-group conv's epilogue produced run-to-run different frames that way in round 5 (isolated launches
+    were always right; DESIGN.md section 4.2 [r5]).  The library therefore contains no such instruction: the build refuses one."""
+    if not os.path.exists(_OBJDUMP):
+        return None
+    import glob
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(obj))
+        os.symlink(os.path.abspath(obj), local)
+        subprocess.run([_OBJDUMP, "--offloading", local], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, cwd=tmp)
+        dev = [f for f in glob.glob(local + ".*") if "amdgcn" in f]
+        if not dev:
+            return None
+        dis = subprocess.run([_OBJDUMP, "-d", dev[0]], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=False).stdout.decode(errors="replace")
+    if "s_endpgm" not in dis:
+        return None
+    return [m.group(0) for m in _WIDE_STORE_SOFF.finditer(dis)]
+
+
 def resource_usage(variant=None):
     """Per-kernel register / scratch / LDS use of the last build (lib/obj*/ *.usage.json, written while compiling)."""
     obj_dir = os.path.join(LIB_DIR, "obj" if variant is None else f"obj_{variant}")
@@ -102,6 +129,24 @@ def build(force=False, verbose=False, variant=None, defines=()):
                                    f"({'no kernels parsed' if not usage else 'unparsed fields for ' + ', '.join(broken[:3])}): the scratch gate cannot vouch for this object")
             with open(os.path.splitext(op)[0] + ".usage.json", "w") as f:
                 json.dump(usage, f, indent=0, sort_keys=True)
+
+    # No wide buffer store with a register scalar offset (wide_stores_with_register_soffset): every .hip object is disassembled once
+    # (report next to the object, redone when the object is newer)
+    for src, op in zip(SOURCES, objs):
+        if not src.endswith(".hip"):
+            continue
+        rp = os.path.splitext(op)[0] + ".stores.json"
+        if not os.path.exists(rp) or os.path.getmtime(rp) < os.path.getmtime(op):
+            hits = wide_stores_with_register_soffset(op)
+            if hits is None:
+                raise RuntimeError(f"{src}: could not disassemble the gfx950 code object (llvm-objdump): the store-hazard gate cannot vouch for this object")
+            with open(rp, "w") as f:
+                json.dump({"wide_stores_with_register_soffset": len(hits), "first": hits[:3]}, f)
+        with open(rp) as f:
+            rep = json.load(f)
+        if rep["wide_stores_with_register_soffset"] and variant is None and not os.environ.get("DSVC_ALLOW_SOFFSET_STORES"):
+            raise RuntimeError(f"{src}: {rep['wide_stores_with_register_soffset']} wide buffer store(s) with a register scalar offset, e.g. `{rep['first'][0]}` "
+                               "-- see build.wide_stores_with_register_soffset")
     # No kernel of this library may touch scratch memory: a kernel that does has lost an array or its accumulators to the stack (once: the
     # generic conv's slab-epilogue variants, 3x slower, unnoticed by every parity test).  DSVC_ALLOW_SCRATCH=1 turns the check off.
     usage_all = resource_usage(variant)

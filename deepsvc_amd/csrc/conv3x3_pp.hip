@@ -89,6 +89,29 @@ constexpr bool PF0_IN_S1 = PP_PF0_IN_S1 != 0;
 #ifndef PP_RES_IN_S1
 #define PP_RES_IN_S1 0
 #endif
+#ifndef PP_PATCH_SOFF       // 1: the tile enters the patch loads as the scalar offset operand (guarded descriptor); 0: added to the vector offset
+#define PP_PATCH_SOFF 1
+#endif
+#ifndef PP_EPI_SOFF         // the same for the epilogue's stores / residual loads
+#define PP_EPI_SOFF 1
+#endif
+// STORES keep the tile offset in the VECTOR offset (one v_add per store).  With the tile offset in the scalar-offset operand (a register)
+// the frame was no longer reproducible: decoded frames differed from run to run by up to 1.0 in millions of elements -- while every launch
+// in isolation, and every synchronised launch inside the frame, was bit-exact (tools/dbg/determinism.py; round 5).  Bisected to exactly
+// this: residual LOADS with a register scalar offset are fine, wide STORES are not.  The generated code issues
+//     buffer_store_dwordx4 v[52:55], v56, s[16:19], s4 offen
+//     v_or_b32 v52, ...                      <- overwrites the store's first data register in the next issue slot
+// back to back: for a wide store WITHOUT a register offset the compiler inserts a wait state here (GCNHazardRecognizer: the 12-dword store
+// hazard is taken to exist only when soffset is not a register); on gfx950 the data registers are evidently still being read in the
+// register-offset case too when the memory pipeline is backed up.  With two wait states pinned behind every such store (-DPP_ST_NOP,
+// PP_EPI_ST_SOFF=1) the frame is reproducible again [see profiles/r05_pp_epilogue_experiments.txt].  deepsvc_amd/build.py refuses any object that contains a
+// wide buffer store with a register scalar offset.
+#ifndef PP_EPI_ST_SOFF
+#define PP_EPI_ST_SOFF 0
+#endif
+#ifndef PP_EPI_LD_SOFF
+#define PP_EPI_LD_SOFF PP_EPI_SOFF
+#endif
 constexpr bool RES_IN_S1 = PP_RES_IN_S1 != 0;
 
 __device__ __forceinline__ void buf_store16(rsrc_t r, unsigned off, uint4 v) {
@@ -113,8 +136,8 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
     // and max commutes with that monotonic rounding, so max(x, f16(x * slope)) == f16(max(x, x * slope)) bit for bit.
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        unsigned t = 0;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "+v"(t) : "v"(u[k]), "v"(slope));
+        unsigned t;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(u[k]), "v"(slope));
         asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(u[k]), "v"(slope));
         asm("v_pk_max_f16 %0, %1, %2" : "=v"(u[k]) : "v"(u[k]), "v"(t));
     }
@@ -128,8 +151,8 @@ __device__ __forceinline__ uint4 act_h16x8(uint4 val, float slope) {
 // tile and wave are the difference between E ~ 4800 and E ~ M.  Numerically the sum is now rounded once (fp32 sum -> f16) instead of twice
 // (fp32 add, then f16): results can differ from the two-step form in the last f16 bit where the fp32-rounded sum sat exactly on an f16 tie.
 __device__ __forceinline__ unsigned mix_pack_add(unsigned r, float x0, float x1) {      // {f16(r.lo + x0), f16(r.hi + x1)}
-    unsigned t = 0;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "+v"(t) : "v"(r), "v"(x0));
+    unsigned t;                          // mixlo writes the low half, mixhi the high half: no zeroing move
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(r), "v"(x0));
     asm("v_fma_mixhi_f16 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(r), "v"(x1));
     return t;
 }
@@ -236,27 +259,60 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
         return TileOrg{rest / tiles_y, ty * PP_TH, tx * 32};
     };
     // patch vector v = gtid + 256*j -> pixel v>>2 (row-major in the 10x34 patch), 16-B quarter v&3
+    // [r5] Addressing diet: an S / E-phase instruction costs 13-20 clocks of issue beside the partner group's prioritised MFMA stream and every
+    // one of them also delays that stream, and the old code spent ~6 vector instructions per load on the address and the border mask plus two
+    // scalar loads of the segment descriptor per chunk and iteration.  Now everything that does not depend on the tile is computed once:
+    // per chunk a buffer descriptor, and per thread and patch vector the byte offset inside the patch pvo[c][j] = patch pixel x pitch +
+    // quarter (| OOB where the vector is statically absent: short chunk, tail of the last vector); the tile enters as the SCALAR offset
+    // operand of the load (tile origin x pitch + chunk), and the border mask is computed only for tiles that touch the image border (a
+    // wave-uniform branch around the mask arithmetic alone: no load sits inside it).  The descriptors start one image row + one pixel
+    // BEFORE the tensor (guard), so the scalar offset of the top-left tile, whose halo starts at pixel (-1, -1), is not negative; the
+    // lanes that would read the guard are exactly the masked padding lanes.
     const int q = gtid & 3;
-    int ppy[PP_PFV], ppx[PP_PFV], pp_pix[PP_PFV];
-#pragma unroll
-    for (int j = 0; j < PP_PFV; ++j) {
-        const int pix = (gtid >> 2) + 64 * j;
-        ppy[j] = pix / PP_PW; ppx[j] = pix - ppy[j] * PP_PW;
-        pp_pix[j] = ppy[j] * W + ppx[j];
-    }
     const bool last_ok = (gtid >> 2) + 64 * (PP_PFV - 1) < PP_NPATCH;      // only the last vector can fall off the patch
-    auto load_chunk = [&](const TileOrg& t, int ch, uint4 (&pf)[PP_PFV]) {
-        const ConvSeg& sg = p.seg[(p.nseg > 1 && ch >= p.seg[1].chunk0) ? 1 : 0];
-        const rsrc_t rin = make_rsrc(sg.ptr, sg.bytes);
-        const unsigned ldb = (unsigned)sg.ld * 2, cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
-        const bool cok = (ch - sg.chunk0) * 32 + q * 8 < sg.C;             // short chunk (C % 8 == 0): the tail reads zeros
-        const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;        // scalar; negative only where inb is false
+    rsrc_t rin_c[NCH];
+    unsigned ldb_c[NCH], sbase_c[NCH], pvo[NCH][PP_PFV];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const ConvSeg& sg = p.seg[(p.nseg > 1 && c >= p.seg[1].chunk0) ? 1 : 0];
+        const unsigned ldb = (unsigned)sg.ld * 2, guard = PP_PATCH_SOFF ? (unsigned)(W + 1) * ldb : 0u;
+        rin_c[c] = make_rsrc((const char*)sg.ptr - guard, sg.bytes + guard);
+        ldb_c[c] = ldb;
+        sbase_c[c] = guard + (unsigned)(c - sg.chunk0) * 64;
+        const bool cok = (c - sg.chunk0) * 32 + q * 8 < sg.C;              // short chunk (C % 8 == 0): the tail reads zeros
+#pragma unroll
+        for (int j = 0; j < PP_PFV; ++j) {
+            const int pix = (gtid >> 2) + 64 * j, py = pix / PP_PW, px = pix - py * PP_PW;
+            pvo[c][j] = ((unsigned)(py * W + px) * ldb + q * 16) | ((cok && (j < PP_PFV - 1 || last_ok)) ? 0u : OOB);
+        }
+    }
+    auto load_chunk = [&](const TileOrg& t, const int ch, uint4 (&pf)[PP_PFV]) {   // ch: a literal at every call site
+        const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;        // scalar; >= -(W + 1): the guard makes the byte offset non-negative
+        const unsigned so = (unsigned)(base_pix * (int)ldb_c[ch]) + sbase_c[ch];
+#ifdef PP_FORCE_EDGE
+        const bool interior = false;
+#else
+        const bool interior = t.oy0 >= 1 && t.oy0 + PP_TH + 1 <= H && t.ox0 >= 1 && t.ox0 + PP_PW - 1 <= W;   // wave-uniform
+#endif
+        unsigned dm[PP_PFV];
+#pragma unroll
+        for (int j = 0; j < PP_PFV; ++j) dm[j] = 0u;
+        if (!interior) {                                                     // image border: padding reads zeros
+            int gt = gtid;
+            asm volatile("" : "+v"(gt));                                     // pins the mask arithmetic INSIDE the branch (it had been hoisted: 24 vector instructions per chunk on every tile)
+#pragma unroll
+            for (int j = 0; j < PP_PFV; ++j) {
+                const int pix = (gt >> 2) + 64 * j, py = pix / PP_PW, px = pix - py * PP_PW;
+                const unsigned iy = (unsigned)(t.oy0 - 1 + py), ix = (unsigned)(t.ox0 - 1 + px);
+                dm[j] = (iy < (unsigned)H && ix < (unsigned)W) ? 0u : OOB;
+            }
+        }
         if (PP_VMEM_PRIO) __builtin_amdgcn_s_setprio(PP_VMEM_PRIO);
 #pragma unroll
         for (int j = 0; j < PP_PFV; ++j) {
-            const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
-            const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PP_PFV - 1 || last_ok) && cok;   // padding reads zeros
-            pf[j] = buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));   // no select of offsets: that becomes an exec-mask branch per load
+            const v4u_t v = PP_PATCH_SOFF ? __builtin_amdgcn_raw_buffer_load_b128(rin_c[ch], pvo[ch][j] | dm[j], so, 0)
+                                          : __builtin_amdgcn_raw_buffer_load_b128(rin_c[ch], ((pvo[ch][j] + so) & 0x7FFFFFFFu) | (pvo[ch][j] & OOB) | dm[j], 0, 0);
+            pf[j] = make_uint4(v.x, v.y, v.z, v.w);
         }
         if (PP_VMEM_PRIO) __builtin_amdgcn_s_setprio(0);
     };
@@ -373,46 +429,65 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
         }
         __builtin_amdgcn_s_setprio(0);
     };
-    // M16 memory layout of a tile row: lane (j, q) <-> pixel 16*half + rho(j), bytes 16*sigma(q) .. +15 of the 64-byte channel group G
-    auto row_off16 = [&](const TileOrg& t, int pb, int ld, bool valid) -> unsigned {
-        const int oy = t.oy0 + wg * MTW + (pb >> 1);                                  // scalar
-        const int px = 16 * (pb & 1) + (QC ? lane >> 2 : rho16);
-        const unsigned pix = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0) + px;
-        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + 16 * (QC ? lane & 3 : sig16)) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
+    // Epilogue addressing [r5: the same diet as the patch loads].  MEMORY layout of a tile row after the swaps: 32x32x16: lane l of vector
+    // `half` holds pixel (l&15) + 16*half, channels 16*((l>>4)&1) + 8*(l>>5) .. +7 of the N-tile (4 lanes cover 64 contiguous bytes of a
+    // pixel, one instruction touches 16 cache lines); 16x16x32: lane (j, q) <-> pixel 16*half + rho(j), bytes 16*sigma(q) .. +15 of the
+    // 64-byte channel group.  Per tensor ONE invariant per-lane byte offset (pixel-in-half x pitch + piece); per tile row m and half a
+    // SCALAR pixel index (x pitch = the scalar offset operand of the store / load) and a mask that is computed only for tiles that touch
+    // the picture's right / bottom edge or have no tile at all.  Index e = 2*m + half (= the 16x16x32 path's pixel block pb).
+    const int px_lane = QC ? lane >> 2 : (M16 ? rho16 : r & 15);
+    const unsigned piece_b = QC ? 16u * (lane & 3) : (M16 ? 16u * sig16 : 32u * (r >> 4) + 16u * h);
+    const unsigned ldo2 = (unsigned)p.out_ld * 2, ld12 = (unsigned)p.res1_ld * 2, ld22 = (unsigned)p.res2_ld * 2;
+    const unsigned evo_out = (unsigned)px_lane * ldo2 + piece_b, evo_r1 = (unsigned)px_lane * ld12 + piece_b, evo_r2 = (unsigned)px_lane * ld22 + piece_b;
+    struct EpiRows { unsigned spix[2 * MTW], dm[2 * MTW]; };
+    auto epi_rows = [&](const TileOrg& t, bool valid, EpiRows& er) {
+#ifdef PP_FORCE_EDGE
+        const bool interior = false;
+#else
+        const bool interior = valid && t.oy0 + PP_TH <= p.Ho && t.ox0 + 32 <= p.Wo;          // wave-uniform
+#endif
+#pragma unroll
+        for (int e = 0; e < 2 * MTW; ++e) {
+            const int oy = t.oy0 + wg * MTW + (e >> 1);                                         // scalar
+            er.spix[e] = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0 + 16 * (e & 1));
+            er.dm[e] = 0u;
+        }
+        if (!interior) {
+            int pl = px_lane;
+            asm volatile("" : "+v"(pl));                                                           // keeps the mask arithmetic inside the branch
+#pragma unroll
+            for (int e = 0; e < 2 * MTW; ++e) {
+                const int oy = t.oy0 + wg * MTW + (e >> 1);
+                er.dm[e] = (valid && oy < p.Ho && t.ox0 + 16 * (e & 1) + pl < p.Wo) ? 0u : OOB;
+            }
+        }
     };
-
-    // epilogue lane roles (after the half-swap): pixel r of the tile row, channels 16*P + 8*h .. +7 of the N-tile
-    // byte offset of this lane's first 8-channel vector (channels 8h..) of tile row m in an NHWC f16 tensor with row
-    // pitch `ld`, or OOB; the other vectors of the pixel sit at constant byte offsets 32*P + 64*N from it (OOB + a
-    // small constant stays out of range, so masked lanes need no further care).  Cout == NT*32 on this path.
-    // MEMORY layout of the epilogue (after the second swap level, v_permlane16_swap on the packed dwords): lane l of
-    // vector `half` holds pixel (l&15) + 16*half of the tile row, channels 16*((l>>4)&1) + 8*(l>>5) .. +7 of the N-tile,
-    // i.e. 4 lanes cover 64 contiguous bytes of a pixel and one instruction touches 16 cache lines instead of 32.
-    auto row_off = [&](const TileOrg& t, int m, int ld, bool valid, int half) -> unsigned {
-        const int oy = t.oy0 + wg * MTW + m;                                          // scalar
-        const int px = (QC ? lane >> 2 : r & 15) + 16 * half;
-        const unsigned pix = (unsigned)((t.b * p.Ho + oy) * p.Wo + t.ox0) + px;
-        return (__umul24(pix & 0xFFFFFFu, (unsigned)ld * 2) + (QC ? 16 * (lane & 3) : 32 * (r >> 4) + 16 * h)) | ((valid && oy < p.Ho && t.ox0 + px < p.Wo) ? 0u : OOB);
+    auto ld16 = [&](rsrc_t rs, unsigned voff, unsigned soff) -> uint4 {
+        const v4u_t v = PP_EPI_LD_SOFF ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0)
+                                    : __builtin_amdgcn_raw_buffer_load_b128(rs, (((voff & 0x7FFFFFFFu) + soff) & 0x7FFFFFFFu) | (voff & OOB), 0, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    auto st16 = [&](rsrc_t rs, unsigned voff, unsigned soff, uint4 v) {
+        v4u_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        if (PP_EPI_ST_SOFF) {
+            __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, 0);
+#ifdef PP_ST_NOP      // experiment: two wait states pinned right behind a store that has a REGISTER scalar offset (see PP_EPI_ST_SOFF)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 1");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        else __builtin_amdgcn_raw_buffer_store_b128(t, rs, (((voff & 0x7FFFFFFFu) + soff) & 0x7FFFFFFFu) | (voff & OOB), 0, 0);
     };
     uint4 res[MTW * NT * 2];
     auto load_res = [&](const TileOrg& t, bool valid, int m0 = 0, int m1 = MTW) {
-        if constexpr (M16) {
+        EpiRows er;
+        epi_rows(t, valid, er);
 #pragma unroll
-            for (int pb = 2 * m0; pb < 2 * m1; ++pb) {
-                const unsigned base = row_off16(t, pb, p.res1_ld, valid);
+        for (int e = 2 * m0; e < 2 * m1; ++e)
 #pragma unroll
-                for (int G = 0; G < NT; ++G) res[pb * NT + G] = buf_load16(rr1, base + 64 * G);
-            }
-            return;
-        }
-#pragma unroll
-        for (int m = m0; m < m1; ++m)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const unsigned base = row_off(t, m, p.res1_ld, valid, half);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) res[(m * NT + n) * 2 + half] = buf_load16(rr1, base + 64 * n);
-            }
+            for (int n = 0; n < NT; ++n)          // M16: res[pb * NT + G]; 32x32x16: res[(m * NT + n) * 2 + half]
+                res[M16 ? e * NT + n : ((e >> 1) * NT + n) * 2 + (e & 1)] = ld16(rr1, (evo_r1 | er.dm[e]) + 64 * n, er.spix[e] * ld12);
     };
 
     // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD x = blockIdx % 8
@@ -531,12 +606,8 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
             PP_HEAD_ROW(0) PP_HEAD_ROW(1)
 #undef PP_HEAD_ROW
         } else if constexpr (M16) {
-            unsigned o_out16[4], o_r216[4];
-#pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                o_out16[pb] = row_off16(cur, pb, p.out_ld, valid);
-                o_r216[pb] = HAS_R2 ? row_off16(cur, pb, p.res2_ld, valid) : OOB;
-            }
+            EpiRows er;
+            epi_rows(cur, valid, er);
             // one v_permlane16_swap per register between the channel blocks 2G (X) and 2G + 1 (Y): X' = rows {X0, Y0, X2, Y2},
             // Y' = rows {X1, Y1, X3, Y3} -> lane row q holds channels 32G + 8*sigma(q) + v in X'[v] and ... + 4 + v in Y'[v]
 #define SWAP16F(X, Y, LO, HI)                                                                                       \
@@ -581,9 +652,9 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
             if constexpr (HAS_R2) {      /* (x + r1) in fp32 -- the bits of the two-step form --, then f16(. + r2) */  \
                 lo[0] = mix_add_lo(ra.x, lo[0]); lo[1] = mix_add_hi(ra.x, lo[1]); lo[2] = mix_add_lo(ra.y, lo[2]); lo[3] = mix_add_hi(ra.y, lo[3]); \
                 hi[0] = mix_add_lo(ra.z, hi[0]); hi[1] = mix_add_hi(ra.z, hi[1]); hi[2] = mix_add_lo(ra.w, hi[2]); hi[3] = mix_add_hi(ra.w, hi[3]); \
-                ra = from_qc(buf_load16(rr2, o_r216[PB] + 64 * G));                                                 \
+                ra = from_qc(ld16(rr2, (evo_r2 | er.dm[PB]) + 64 * G, er.spix[PB] * ld22));                                                 \
             }                                                                                                       \
-            buf_store16(rout, o_out16[PB] + 64 * G, to_qc(make_uint4(mix_pack_add(ra.x, lo[0], lo[1]), mix_pack_add(ra.y, lo[2], lo[3]),   \
+            st16(rout, (evo_out | er.dm[PB]) + 64 * G, er.spix[PB] * ldo2, to_qc(make_uint4(mix_pack_add(ra.x, lo[0], lo[1]), mix_pack_add(ra.y, lo[2], lo[3]),   \
                                                                      mix_pack_add(ra.z, hi[0], hi[1]), mix_pack_add(ra.w, hi[2], hi[3]))));  \
         } else {                                                                                                    \
         if constexpr (HAS_R1) {                                                                                     \
@@ -591,12 +662,12 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
             lo[0] += h16_lo(ra.x); lo[1] += h16_hi(ra.x); lo[2] += h16_lo(ra.y); lo[3] += h16_hi(ra.y);             \
             hi[0] += h16_lo(ra.z); hi[1] += h16_hi(ra.z); hi[2] += h16_lo(ra.w); hi[3] += h16_hi(ra.w);             \
             if constexpr (HAS_R2) {                                                                                 \
-                const uint4 ca = from_qc(buf_load16(rr2, o_r216[PB] + 64 * G));                                     \
+                const uint4 ca = from_qc(ld16(rr2, (evo_r2 | er.dm[PB]) + 64 * G, er.spix[PB] * ld22));                                     \
                 lo[0] += h16_lo(ca.x); lo[1] += h16_hi(ca.x); lo[2] += h16_lo(ca.y); lo[3] += h16_hi(ca.y);         \
                 hi[0] += h16_lo(ca.z); hi[1] += h16_hi(ca.z); hi[2] += h16_lo(ca.w); hi[3] += h16_hi(ca.w);         \
             }                                                                                                       \
         }                                                                                                           \
-        buf_store16(rout, o_out16[PB] + 64 * G, to_qc(make_uint4(pk_h16(lo[0], lo[1]), pk_h16(lo[2], lo[3]), pk_h16(hi[0], hi[1]), pk_h16(hi[2], hi[3])))); \
+        st16(rout, (evo_out | er.dm[PB]) + 64 * G, er.spix[PB] * ldo2, to_qc(make_uint4(pk_h16(lo[0], lo[1]), pk_h16(lo[2], lo[3]), pk_h16(hi[0], hi[1]), pk_h16(hi[2], hi[3])))); \
         }                                                                                                           \
     }
             PP16_OUT(0, 0) PP16_OUT(0, 1) PP16_OUT(1, 0) PP16_OUT(1, 1) PP16_OUT(2, 0) PP16_OUT(2, 1) PP16_OUT(3, 0) PP16_OUT(3, 1)
@@ -604,14 +675,8 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
 #undef PP16_GATHER
 #undef SWAP16F
         } else {
-            unsigned o_out[MTW][2], o_r2[MTW][2];
-#pragma unroll
-            for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    o_out[m][half] = row_off(cur, m, p.out_ld, valid, half);
-                    o_r2[m][half] = HAS_R2 ? row_off(cur, m, p.res2_ld, valid, half) : OOB;
-                }
+            EpiRows er;
+            epi_rows(cur, valid, er);
             // One 32x32 accumulator tile (tile row M, N-tile N) at a time, written out with static indices (a rolled loop
             // would push acc[][] to scratch).  COMPUTE layout after the first swap level: lane (r, h) holds, for
             // P = 0, 1, the 8 channels 16P + 8h .. +7 of pixel r (v0 / v1).  Residuals arrive in the memory layout
@@ -644,7 +709,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
                     v0[2 * j] = mix_add_lo(xa[j], v0[2 * j]); v0[2 * j + 1] = mix_add_hi(xa[j], v0[2 * j + 1]);     \
                     v1[2 * j] = mix_add_lo(xb[j], v1[2 * j]); v1[2 * j + 1] = mix_add_hi(xb[j], v1[2 * j + 1]);     \
                 }                                                                                                   \
-                const uint4 ca = from_qc(buf_load16(rr2, o_r2[M][0] + 64 * N)), cb = from_qc(buf_load16(rr2, o_r2[M][1] + 64 * N));   \
+                const uint4 ca = from_qc(ld16(rr2, (evo_r2 | er.dm[2 * M]) + 64 * N, er.spix[2 * M] * ld22)), cb = from_qc(ld16(rr2, (evo_r2 | er.dm[2 * M + 1]) + 64 * N, er.spix[2 * M + 1] * ld22));   \
                 const unsigned na[4] = {ca.x, ca.y, ca.z, ca.w}, nb[4] = {cb.x, cb.y, cb.z, cb.w};                  \
                 _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(na[d], nb[d], xa[d], xb[d])                    \
             }                                                                                                       \
@@ -663,7 +728,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
                 v1[2 * j] += h16_lo(xb[j]); v1[2 * j + 1] += h16_hi(xb[j]); \
             }                                                                                                       \
             if constexpr (HAS_R2) {                                                                                 \
-                const uint4 ca = from_qc(buf_load16(rr2, o_r2[M][0] + 64 * N)), cb = from_qc(buf_load16(rr2, o_r2[M][1] + 64 * N));   \
+                const uint4 ca = from_qc(ld16(rr2, (evo_r2 | er.dm[2 * M]) + 64 * N, er.spix[2 * M] * ld22)), cb = from_qc(ld16(rr2, (evo_r2 | er.dm[2 * M + 1]) + 64 * N, er.spix[2 * M + 1] * ld22));   \
                 const unsigned na[4] = {ca.x, ca.y, ca.z, ca.w}, nb[4] = {cb.x, cb.y, cb.z, cb.w};                  \
                 unsigned ya[4], yb[4];                                                                              \
                 _Pragma("unroll") for (int d = 0; d < 4; ++d) SWAP16(na[d], nb[d], ya[d], yb[d])                    \
@@ -678,8 +743,8 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
         unsigned s0[4], s1[4];                                                                                      \
         _Pragma("unroll") for (int d = 0; d < 4; ++d)                                                               \
             SWAP16(p0[d], p1[d], s0[d], s1[d])                                                                      \
-        buf_store16(rout, o_out[M][0] + 64 * N, to_qc(make_uint4(s0[0], s0[1], s0[2], s0[3])));                     \
-        buf_store16(rout, o_out[M][1] + 64 * N, to_qc(make_uint4(s1[0], s1[1], s1[2], s1[3])));                     \
+        st16(rout, (evo_out | er.dm[2 * M]) + 64 * N, er.spix[2 * M] * ldo2, to_qc(make_uint4(s0[0], s0[1], s0[2], s0[3])));                     \
+        st16(rout, (evo_out | er.dm[2 * M + 1]) + 64 * N, er.spix[2 * M + 1] * ldo2, to_qc(make_uint4(s1[0], s1[1], s1[2], s1[3])));                     \
     }
             if constexpr (POST) {
                 static_assert(!POST || NT == 2, "fused 1x1: 64 -> 64 channels");
@@ -818,6 +883,13 @@ int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;   // pixel indices go through the 24-bit multiplier
     if (ntiles < 1024) return 1;           // small images: the generic kernel's finer tiling fills the chip better
+#ifdef DSVC_PP_DBG_SKIP                    // debug build: DSVC_PP_SKIP=<bits> hands a class of launches back to the other kernels (1 head, 2 fused tail, 4 one-chunk, 8 residual, 16 the rest)
+    {
+        static const int skip = getenv("DSVC_PP_SKIP") ? atoi(getenv("DSVC_PP_SKIP")) : 0;
+        const int cls = d->Cout <= 8 ? 1 : d->post_weight ? 2 : p.nchunks == 1 ? 4 : d->res1 ? 8 : 16;
+        if (skip & cls) return 1;
+    }
+#endif
     if (d->post_weight) {                  // fused ResBottleneck tail: conv3x3 -> act -> conv1x1 -> + residual
         float a_slope;
         if (p.nchunks != 2 || d->Cout != 64 || d->pre_act != DSVC_ACT_NONE || d->res2 || !slope_of(d->act, d->slope, &a_slope)) return 1;

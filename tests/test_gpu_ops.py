@@ -1138,6 +1138,51 @@ def test_pp_kernel_mfma_shapes_agree():
         ops.set_precision("fp32")
 
 
+def test_pp_kernel_touches_nothing_outside_its_tensors():
+    """Round 5: the two-group 3x3 kernel's patch loads take the tile origin as the SCALAR offset of a descriptor that starts one image row + one
+    pixel before the tensor (csrc/conv3x3_pp.hip: addressing diet), and the hardware range check covers only the vector offset: whatever must
+    not be read or written is masked by the kernel itself.  Input, residual and output are carved out of ONE buffer full of NaN (4 M elements
+    of NaN between them): the result must equal the run on stand-alone tensors bit for bit, contain no NaN, and leave every NaN around the
+    tensors in place -- for the plain, one-chunk, residual, 32-channel and narrow-head variants at the frame's 256x1024 shape."""
+    from deepsvc_amd import _native as N, ops
+    from deepsvc_amd.modules import Conv2d
+    ops.set_precision("f16")
+    h = torch.float16
+    try:
+        H, W = 256, 1024
+        torch.manual_seed(0)
+        for name, cin, cout, kw_f in [("plain 64->64", 64, 64, lambda r: {}), ("act 64->64", 64, 64, lambda r: dict(act=N.ACT_LRELU, slope=0.01)),
+                                      ("32->64", 32, 64, lambda r: dict(act=N.ACT_RELU)), ("16->64", 16, 64, lambda r: {}), ("res1", 64, 64, lambda r: dict(res1=r)),
+                                      ("64->32", 64, 32, lambda r: {}), ("head 64->3", 64, 3, lambda r: {})]:
+            conv = Conv2d(cin, cout, 3, 1, 1).to(DEV)
+            x_clean = torch.randn((1, H, W, cin), device=DEV).to(h)
+            r_clean = torch.randn((1, H, W, cout), device=DEV).to(h)
+            odt = torch.float32 if cout <= 8 else h
+            before = ops.get_counter("conv3x3_pp")
+            ref = conv.run(ops.Act(x_clean), out_dtype=odt, **kw_f(ops.Act(r_clean))).buf.clone()
+            assert ops.get_counter("conv3x3_pp") == before + 1, f"{name}: the two-group kernel did not take this launch"
+            pad = 4 * 1024 * 1024
+            big = torch.full((pad * 4 + H * W * (cin + 2 * 64) + 64,), float("nan"), device=DEV, dtype=h)
+            xo, ro, oo = pad, 2 * pad + H * W * cin, 3 * pad + H * W * (cin + 64)
+            carve = lambda off, C: big[off:off + H * W * C].view(1, H, W, C)
+            x = carve(xo, cin); x.copy_(x_clean)
+            r = carve(ro, cout); r.copy_(r_clean)
+            if odt == h:
+                out = conv.run(ops.Act(x), ops.Act(carve(oo, cout)), out_dtype=h, **kw_f(ops.Act(r))).buf
+            else:
+                out = conv.run(ops.Act(x), out_dtype=odt, **kw_f(ops.Act(r))).buf
+            torch.cuda.synchronize()
+            assert not bool(torch.isnan(out.float()).any()), f"{name}: NaN from outside the tensors reached the output"
+            assert torch.equal(out, ref), f"{name}: differs from the run on stand-alone tensors"
+            mask = torch.ones_like(big, dtype=torch.bool)
+            mask[xo:xo + H * W * cin] = False; mask[ro:ro + H * W * cout] = False
+            if odt == h:
+                mask[oo:oo + H * W * cout] = False
+            assert bool(torch.isnan(big[mask]).all()), f"{name}: wrote outside its output tensor"
+    finally:
+        ops.set_precision("fp32")
+
+
 def test_pp_kernel_mixed_precision_residual_epilogue():
     """Option pp_mix (round 5): f16(x + r) of the two-group 3x3 kernel's residual variants as v_fma_mixlo_f16 / v_fma_mixhi_f16 (the f16
     residual enters the FMA directly, the fp32 sum is rounded ONCE to f16) instead of cvt + add + cvt_pk (rounded to fp32, then to f16).
