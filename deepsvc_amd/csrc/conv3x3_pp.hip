@@ -89,6 +89,10 @@ constexpr bool PF0_IN_S1 = PP_PF0_IN_S1 != 0;
 #ifndef PP_RES_IN_S1
 #define PP_RES_IN_S1 0
 #endif
+#ifndef PP_POST_IN_M1       // fused 1x1 tail: its GEMM at the end of the wave's own M1 phase (1) or in the E phase (0: rounds 2-4)
+#define PP_POST_IN_M1 1
+#endif
+constexpr bool POST_IN_M1 = PP_POST_IN_M1 != 0;
 #ifndef PP_PATCH_SOFF       // 1: the tile enters the patch loads as the scalar offset operand (guarded descriptor); 0: added to the vector offset
 #define PP_PATCH_SOFF 1
 #endif
@@ -490,6 +494,91 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
                 res[M16 ? e * NT + n : ((e >> 1) * NT + n) * 2 + (e & 1)] = ld16(rr1, (evo_r1 | er.dm[e]) + 64 * n, er.spix[e] * ld12);
     };
 
+    // ---- POST: the fused 1x1 conv (ResBottleneckBlock.conv3) on the activated tile ----
+    // [r5] It runs at the END of the wave's own M1 phase (PP_POST_IN_M1), not in the E phase: there its 16 MFMAs per wave queued behind the
+    // partner group's prioritised MFMA stream and the E phase took 6000-7000 clocks against 3000 for M (in-kernel stamps,
+    // profiles/r05_pp_phase_probe.txt); in M1 the wave owns the matrix pipe anyway and its partner is in the short S1 phase.
+    static_assert(!POST || NT == 2, "fused 1x1: 64 -> 64 channels");
+    auto post_gemm = [&]() {
+        if constexpr (POST && M16) {
+            __builtin_amdgcn_s_setprio(PP_M_PRIO);
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                uint4 bfr[2];                // B fragments of the 1x1's two k-groups: act(conv3x3 + bias), packed f16
+#pragma unroll
+                for (int G = 0; G < 2; ++G) {
+                    float lo[4], hi[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {       // one v_permlane16_swap per register between the channel blocks 2G and 2G + 1 (see the epilogue)
+                        const float xq = acc16[pb][2 * G][v], yq = acc16[pb][2 * G + 1][v];
+                        const v2u_t sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false);
+                        const unsigned lo_ = sw.x, hi_ = sw.y;
+                        lo[v] = __builtin_bit_cast(float, lo_); hi[v] = __builtin_bit_cast(float, hi_);
+                    }
+                    if constexpr (ACT) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) { lo[v] = lrelu_f(lo[v], act_slope); hi[v] = lrelu_f(hi[v], act_slope); }
+                    }
+                    bfr[G] = make_uint4(pk_h16(lo[0], lo[1]), pk_h16(lo[2], lo[3]), pk_h16(hi[0], hi[1]), pk_h16(hi[2], hi[3]));
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {     // accumulators of the 1x1 start as its bias
+                    const float4 bq = *(const float4*)(lds_bias + NTN + 16 * cb + 4 * q16);
+                    acc16[pb][cb][0] = bq.x; acc16[pb][cb][1] = bq.y; acc16[pb][cb][2] = bq.z; acc16[pb][cb][3] = bq.w;
+                }
+#pragma unroll
+                for (int G = 0; G < 2; ++G)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const uint4 wf = *(const uint4*)(lds_w3 + (G * NTN + 16 * cb + rho16) * ROWB + 16 * sig16);
+                        acc16[pb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf), __builtin_bit_cast(h16x8, bfr[G]), acc16[pb][cb], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else if constexpr (POST) {
+            __builtin_amdgcn_s_setprio(PP_M_PRIO);
+#pragma unroll
+            for (int M = 0; M < MTW; ++M) {
+                unsigned bfr[4][4];          // B fragments of k-blocks 0..3: act(conv3x3 + bias) of pixel r, packed f16
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int P = 0; P < 2; ++P) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xq = acc[M][n][8 * P + j], yq = acc[M][n][8 * P + 4 + j];
+                            const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false);
+                            const unsigned lo_ = sw.x, hi_ = sw.y;
+                            v[j] = __builtin_bit_cast(float, lo_); v[4 + j] = __builtin_bit_cast(float, hi_);
+                        }
+                        if constexpr (ACT) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = lrelu_f(v[j], act_slope);
+                        }
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) bfr[2 * n + P][d] = pk_h16(v[2 * d], v[2 * d + 1]);
+                    }
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2)       // accumulators of the 1x1 start as its bias
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const float4 bq = *(const float4*)(lds_bias + NTN + n2 * 32 + 8 * qd + 4 * h);
+                        acc[M][n2][4 * qd] = bq.x; acc[M][n2][4 * qd + 1] = bq.y; acc[M][n2][4 * qd + 2] = bq.z; acc[M][n2][4 * qd + 3] = bq.w;
+                    }
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int n2 = 0; n2 < 2; ++n2) {
+                        const uint4 wf = *(const uint4*)(lds_w3 + ((kb >> 1) * NTN + n2 * 32 + r) * ROWB + (kb & 1) * 32 + h * 16);
+                        const uint4 bf4 = make_uint4(bfr[kb][0], bfr[kb][1], bfr[kb][2], bfr[kb][3]);
+                        acc[M][n2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wf), __builtin_bit_cast(h16x8, bf4), acc[M][n2], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
     // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD x = blockIdx % 8
     // takes the x-th contiguous eighth of the tile raster (a band of tile rows) and its 32 workgroups x 2 groups sweep
     // that band ~one tile row per iteration: the halo rows shared by vertically adjacent tiles are then re-read from
@@ -578,6 +667,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
             PP_BARRIER(1)
             // ---- M1 ----
             if constexpr (M16) mfma_phase16(1, false); else mfma_phase(1, false);
+            if constexpr (POST && POST_IN_M1) post_gemm();
             PP_BARRIER(2)
         }
         // ---- E + S0 (+ prefetch: chunk 0 of the tile after next, the next tile's residual) ----
@@ -616,30 +706,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
       const unsigned lo_ = sw.x, hi_ = sw.y; (LO) = __builtin_bit_cast(float, lo_); (HI) = __builtin_bit_cast(float, hi_); }
 #define PP16_GATHER(PB, G, LO, HI)                                                                                  \
     _Pragma("unroll") for (int v = 0; v < 4; ++v) SWAP16F(acc16[PB][2 * (G)][v], acc16[PB][2 * (G) + 1][v], LO[v], HI[v])
-            if constexpr (POST) {
-                static_assert(!POST || NT == 2, "fused 1x1: 64 -> 64 channels");
-#define PP16_POST(PB)                                                                                               \
-    {                                                                                                               \
-        uint4 bfr[2];                /* B fragments of the 1x1's two k-groups: act(conv3x3 + bias), packed f16 */        \
-        _Pragma("unroll") for (int G = 0; G < 2; ++G) {                                                             \
-            float lo[4], hi[4];                                                                                     \
-            PP16_GATHER(PB, G, lo, hi)                                                                              \
-            if constexpr (ACT) { _Pragma("unroll") for (int v = 0; v < 4; ++v) { lo[v] = lrelu_f(lo[v], act_slope); hi[v] = lrelu_f(hi[v], act_slope); } } \
-            bfr[G] = make_uint4(pk_h16(lo[0], lo[1]), pk_h16(lo[2], lo[3]), pk_h16(hi[0], hi[1]), pk_h16(hi[2], hi[3]));   \
-        }                                                                                                           \
-        _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {     /* accumulators of the 1x1 start as its bias */          \
-            const float4 bq = *(const float4*)(lds_bias + NTN + 16 * cb + 4 * q16);                                 \
-            acc16[PB][cb][0] = bq.x; acc16[PB][cb][1] = bq.y; acc16[PB][cb][2] = bq.z; acc16[PB][cb][3] = bq.w;     \
-        }                                                                                                           \
-        _Pragma("unroll") for (int G = 0; G < 2; ++G)                                                               \
-            _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) {                                                      \
-                const uint4 wf = *(const uint4*)(lds_w3 + (G * NTN + 16 * cb + rho16) * ROWB + 16 * sig16);         \
-                acc16[PB][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf), __builtin_bit_cast(h16x8, bfr[G]), acc16[PB][cb], 0, 0, 0); \
-            }                                                                                                       \
-    }
-                PP16_POST(0) PP16_POST(1) PP16_POST(2) PP16_POST(3)
-#undef PP16_POST
-            }
+            if constexpr (POST && !POST_IN_M1) post_gemm();
 #define PP16_OUT(PB, G)                                                                                             \
     if constexpr (G < NT) {                                                                                         \
         float lo[4], hi[4];                                                                                         \
@@ -746,39 +813,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
         st16(rout, (evo_out | er.dm[2 * M]) + 64 * N, er.spix[2 * M] * ldo2, to_qc(make_uint4(s0[0], s0[1], s0[2], s0[3])));                     \
         st16(rout, (evo_out | er.dm[2 * M + 1]) + 64 * N, er.spix[2 * M + 1] * ldo2, to_qc(make_uint4(s1[0], s1[1], s1[2], s1[3])));                     \
     }
-            if constexpr (POST) {
-                static_assert(!POST || NT == 2, "fused 1x1: 64 -> 64 channels");
-#define PP_POST_ROW(M)                                                                                              \
-    {                                                                                                               \
-        unsigned bfr[4][4];          /* B fragments of k-blocks 0..3: act(conv3x3 + bias) of pixel r, packed f16 */    \
-        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                               \
-            _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                         \
-                float v[8];                                                                                         \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
-                    const float xq = acc[M][n][8 * P + j], yq = acc[M][n][8 * P + 4 + j];                           \
-                    const v2u_t sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xq), __builtin_bit_cast(unsigned, yq), false, false); \
-                    const unsigned lo_ = sw.x, hi_ = sw.y;                                                          \
-                    v[j] = __builtin_bit_cast(float, lo_); v[4 + j] = __builtin_bit_cast(float, hi_);               \
-                }                                                                                                   \
-                if constexpr (ACT) { _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = lrelu_f(v[j], act_slope); } \
-                _Pragma("unroll") for (int d = 0; d < 4; ++d) bfr[2 * n + P][d] = pk_h16(v[2 * d], v[2 * d + 1]);    \
-            }                                                                                                       \
-        _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) {     /* accumulators of the 1x1 start as its bias */        \
-            _Pragma("unroll") for (int qd = 0; qd < 4; ++qd) {                                                      \
-                const float4 bq = *(const float4*)(lds_bias + NTN + n2 * 32 + 8 * qd + 4 * h);                      \
-                acc[M][n2][4 * qd] = bq.x; acc[M][n2][4 * qd + 1] = bq.y; acc[M][n2][4 * qd + 2] = bq.z; acc[M][n2][4 * qd + 3] = bq.w; \
-            }                                                                                                       \
-        }                                                                                                           \
-        _Pragma("unroll") for (int kb = 0; kb < 4; ++kb)                                                            \
-            _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2) {                                                      \
-                const uint4 wf = *(const uint4*)(lds_w3 + ((kb >> 1) * NTN + n2 * 32 + r) * ROWB + (kb & 1) * 32 + h * 16); \
-                const uint4 bf4 = make_uint4(bfr[kb][0], bfr[kb][1], bfr[kb][2], bfr[kb][3]);                       \
-                acc[M][n2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wf), __builtin_bit_cast(h16x8, bf4), acc[M][n2], 0, 0, 0); \
-            }                                                                                                       \
-    }
-                PP_POST_ROW(0) PP_POST_ROW(1)
-#undef PP_POST_ROW
-            }
+            if constexpr (POST && !POST_IN_M1) post_gemm();
             PP_TILE(0, 0) PP_TILE(0, 1) PP_TILE(1, 0) PP_TILE(1, 1)
 #undef PP_TILE
 #undef SWAP16
