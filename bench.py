@@ -43,8 +43,8 @@ HBM_PEAK = 8.0e12                                    # B/s
 FLOP_PER_PX = {2: 8.571e6,      # GOP = 7: mean over the 6 P-frames (first P 8.453e6, steady-state 8.594e6)
                3: 8.076e6}      # GOP = 12 with the intra-coded key frame: mean over all 12 frames
 GOP_OF = {2: 7, 3: 12}
-PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_dominant_kernel_pmc.json") for r in (4, 3, 2)) if os.path.exists(p)),
-                os.path.join(ROOT, "profiles", "r04_dominant_kernel_pmc.json"))
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_dominant_kernel_pmc.json") for r in (5, 4, 3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r05_dominant_kernel_pmc.json"))
 
 
 def parse():
