@@ -39,7 +39,7 @@ void dsvc_set_error(const char* fmt, ...);
 #endif
 // ---- kernel-selection switches of dsvc_conv2d (dsvc_set_option, host_misc.cpp) ------------------
 struct DsvcOptions {
-    int specialised, pp, ws, conv1x1, ws_waves4, ws_direct_store, tall_min_tiles, reg_epilogue, patch_prefetch, pp16, epi_f32, shuffle_vec, head, conv1x1_rows, small_pf, pps, pps_f32, conv1x1_f32, head_f32, skip_zero_k, pp_qc, pp_mix;
+    int specialised, pp, ws, conv1x1, ws_waves4, ws_direct_store, tall_min_tiles, reg_epilogue, patch_prefetch, pp16, epi_f32, shuffle_vec, head, conv1x1_rows, small_pf, pps, pps_f32, conv1x1_f32, head_f32, skip_zero_k, pp_qc, pp_mix, pps_oneseg;
 };
 extern DsvcOptions g_dsvc_opt;
 

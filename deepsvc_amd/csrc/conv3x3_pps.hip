@@ -87,7 +87,12 @@ __device__ __forceinline__ uint4 ps_act_h16x8(uint4 val, float slope) {
 // the byte-identity tests against the reference green.
 // EXT (f16 only) [r4]: output-channel split (96 / 128 output channels as two passes of 64), pre-activation on the staged patch, one f16 residual.
 // Kept out of the plain instantiations at compile time: they sit at 238-244 VGPRs and the extra address arithmetic spilled them.
-template <typename CT, bool ACT, bool EXT = false, bool R1P = false>
+// ONESEG [r5]: one input segment (the fp32 64 -> 64 family, the f16 128 -> 128 split): the patch requests use tile-invariant addressing as in
+// conv3x3_pp.hip -- descriptor (one image row + one pixel of guard in front), per-thread vector offsets and static masks computed once, the tile
+// and the chunk in the SCALAR offset operand, border masks only on border tiles.  The fp32 instantiation issues its requests from inside the
+// M phase, one per k-step, and each one used to re-read the segment descriptor from the kernel arguments (two scalar loads + a wait) and
+// spend ~9 vector instructions on address and mask: the wave's own MFMA stream paid 110-150 clocks per request (tools/pps_phase_probe.py).
+template <typename CT, bool ACT, bool EXT = false, bool R1P = false, bool ONESEG = false>
 __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p, int ntiles, int iters, float act_slope, int nsplit_arg) {
     DSVC_F16_SAT();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,43 +129,72 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
     };
     // ---- patch staging (as conv3x3_pp.hip): vector v = gtid + 256 j -> patch pixel v >> 2, 16-byte quarter v & 3 ----
     const int q = gtid & 3;
-    int ppy[PS_PFV], ppx[PS_PFV], pp_pix[PS_PFV];
-#pragma unroll
-    for (int j = 0; j < PS_PFV; ++j) {
-        const int pix = (gtid >> 2) + 64 * j;
-        ppy[j] = pix / PS_PW; ppx[j] = pix - ppy[j] * PS_PW;
-        pp_pix[j] = ppy[j] * W + ppx[j];
-    }
     const bool last_ok = (gtid >> 2) + 64 * (PS_PFV - 1) < PS_NPATCH;
-    auto load_chunk = [&](const TileOrg& t, int ch, uint4 (&pf)[PS_PFV]) {
-        int si = 0;
-        if (p.nseg > 1 && ch >= p.seg[1].chunk0) si = 1;
-        if (p.nseg > 2 && ch >= p.seg[2].chunk0) si = 2;
-        const ConvSeg& sg = p.seg[si];
-        const rsrc_t rin = make_rsrc(sg.ptr, sg.bytes);
-        const unsigned ldb = (unsigned)sg.ld * (unsigned)sizeof(CT), cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
-        const bool cok = (ch - sg.chunk0) * KCE + q * EPV < sg.C;          // short chunk (C % EPV == 0): the tail reads zeros
-        const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;
+    // pixel offset of this thread's patch vector j inside the patch, in pixels of the image (py * W + px)
+    auto patch_pix = [&](int j) { const int pix = (gtid >> 2) + 64 * j, py = pix / PS_PW; return py * W + (pix - py * PS_PW); };
+    // border mask of patch vector j of tile t (only evaluated on border tiles: the arithmetic is pinned inside the wave-uniform branch)
+    auto border_mask = [&](const TileOrg& t, int gt, int j) -> unsigned {
+        const int pix = (gt >> 2) + 64 * j, py = pix / PS_PW, px = pix - py * PS_PW;
+        const unsigned iy = (unsigned)(t.oy0 - 1 + py), ix = (unsigned)(t.ox0 - 1 + px);
+        return (iy < (unsigned)H && ix < (unsigned)W) ? 0u : OOB;
+    };
+    auto tile_interior = [&](const TileOrg& t) { return t.oy0 >= 1 && t.oy0 + PS_TH + 1 <= H && t.ox0 >= 1 && t.ox0 + PS_PW - 1 <= W; };
+    // ONESEG: everything tile-invariant once
+    const ConvSeg& sg0 = p.seg[0];
+    const unsigned ldb0 = (unsigned)sg0.ld * (unsigned)sizeof(CT), guard0 = (unsigned)(W + 1) * ldb0;
+    const rsrc_t rin0 = make_rsrc((const char*)sg0.ptr - guard0, sg0.bytes + guard0);
+    unsigned pvo[ONESEG ? PS_PFV : 1];
+    int pp_pix[ONESEG ? 1 : PS_PFV];
+    if constexpr (ONESEG) {
 #pragma unroll
-        for (int j = 0; j < PS_PFV; ++j) {
-            const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
-            const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PS_PFV - 1 || last_ok) && cok;
-            pf[j] = buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));
+        for (int j = 0; j < PS_PFV; ++j) pvo[j] = ((unsigned)patch_pix(j) * ldb0 + q * 16) | ((j < PS_PFV - 1 || last_ok) ? 0u : OOB);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PS_PFV; ++j) pp_pix[j] = patch_pix(j);
+    }
+    // one patch vector: descriptor / pitch / chunk of segment `si` are looked up per call when there are several segments
+    auto load_vec = [&](const TileOrg& t, int ch, int j, unsigned dm) -> uint4 {
+        const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;        // scalar; >= -(W + 1): the guard makes the byte offset non-negative
+        if constexpr (ONESEG) {
+            const unsigned cokm = (ch * KCE + q * EPV < sg0.C) ? 0u : OOB;   // short chunk (C % EPV == 0): the tail reads zeros
+            const unsigned so = (unsigned)(base_pix * (int)ldb0) + guard0 + (unsigned)ch * 64u;
+            const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rin0, pvo[j] | cokm | dm, so, 0);
+            return make_uint4(v.x, v.y, v.z, v.w);
+        } else {
+            int si = 0;
+            if (p.nseg > 1 && ch >= p.seg[1].chunk0) si = 1;
+            if (p.nseg > 2 && ch >= p.seg[2].chunk0) si = 2;
+            const ConvSeg& sg = p.seg[si];
+            const unsigned ldb = (unsigned)sg.ld * (unsigned)sizeof(CT), guard = (unsigned)(W + 1) * ldb;
+            const rsrc_t rin = make_rsrc((const char*)sg.ptr - guard, sg.bytes + guard);
+            const unsigned cokm = ((ch - sg.chunk0) * KCE + q * EPV < sg.C && (j < PS_PFV - 1 || last_ok)) ? 0u : OOB;
+            const unsigned so = (unsigned)(base_pix * (int)ldb) + guard + (unsigned)(ch - sg.chunk0) * 64u;
+            const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(rin, (__umul24((unsigned)pp_pix[j], ldb) + q * 16) | cokm | dm, so, 0);
+            return make_uint4(v.x, v.y, v.z, v.w);
         }
+    };
+    auto load_chunk = [&](const TileOrg& t, int ch, uint4 (&pf)[PS_PFV]) {
+        unsigned dm[PS_PFV];
+#pragma unroll
+        for (int j = 0; j < PS_PFV; ++j) dm[j] = 0u;
+        if (!tile_interior(t)) {                                             // wave-uniform
+            int gt = gtid;
+            asm volatile("" : "+v"(gt));
+#pragma unroll
+            for (int j = 0; j < PS_PFV; ++j) dm[j] = border_mask(t, gt, j);
+        }
+#pragma unroll
+        for (int j = 0; j < PS_PFV; ++j) pf[j] = load_vec(t, ch, j, dm[j]);
     };
     // one vector of load_chunk (fp32: the requests are issued from inside the M phase, one per k-step -- see mfma_phase)
     auto load_chunk_one = [&](const TileOrg& t, int ch, int j) -> uint4 {
-        int si = 0;
-        if (p.nseg > 1 && ch >= p.seg[1].chunk0) si = 1;
-        if (p.nseg > 2 && ch >= p.seg[2].chunk0) si = 2;
-        const ConvSeg& sg = p.seg[si];
-        const rsrc_t rin = make_rsrc(sg.ptr, sg.bytes);
-        const unsigned ldb = (unsigned)sg.ld * (unsigned)sizeof(CT), cb = (unsigned)(ch - sg.chunk0) * 64 + q * 16;
-        const bool cok = (ch - sg.chunk0) * KCE + q * EPV < sg.C;
-        const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;
-        const unsigned iy = (unsigned)(t.oy0 - 1 + ppy[j]), ix = (unsigned)(t.ox0 - 1 + ppx[j]);
-        const bool inb = iy < (unsigned)H && ix < (unsigned)W && (j < PS_PFV - 1 || last_ok) && cok;
-        return buf_load16(rin, (__umul24((unsigned)(base_pix + pp_pix[j]) & 0xFFFFFFu, ldb) + cb) | (inb ? 0u : OOB));
+        unsigned dm = 0u;
+        if (!tile_interior(t)) {
+            int gt = gtid;
+            asm volatile("" : "+v"(gt));
+            dm = border_mask(t, gt, j);
+        }
+        return load_vec(t, ch, j, dm);
     };
     const float pre_sl = p.pre_act == DSVC_ACT_RELU ? 0.f : p.slope;
     auto store_chunk = [&](uint4 (&pf)[PS_PFV]) {
@@ -579,11 +613,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pps_kernel(const ConvParams p,
 #undef PS_SWAP32
 }
 
-template <typename CT, bool ACT, bool EXT = false, bool R1P = false>
+template <typename CT, bool ACT, bool EXT = false, bool R1P = false, bool ONESEG = false>
 int launch_pps(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, int nsplit = 1) {
+    if constexpr (!ONESEG) {
+        if (p.nseg == 1 && g_dsvc_opt.pps_oneseg) return launch_pps<CT, ACT, EXT, R1P, true>(st, p, ntiles, act_slope, nsplit);
+    }
     const size_t lds = (size_t)2 * PS_WBYTES + (size_t)2 * PS_NPATCH * ROWB + (size_t)PS_NTN * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv3x3_pps_kernel<CT, ACT, EXT, R1P>;
+    auto kern = conv3x3_pps_kernel<CT, ACT, EXT, R1P, ONESEG>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }

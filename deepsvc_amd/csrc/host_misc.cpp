@@ -25,7 +25,7 @@ DsvcOptions g_dsvc_opt = {
     /*ws_waves4*/ env_flag("DSVC_WS_WAVES4"), /*ws_direct_store*/ env_flag("DSVC_WS_DIRECT"),
     /*tall_min_tiles*/ getenv("DSVC_TALL_MIN_TILES") ? atoi(getenv("DSVC_TALL_MIN_TILES")) : 1024,
     /*reg_epilogue*/ !env_flag("DSVC_NO_REGEPI"), /*patch_prefetch*/ !env_flag("DSVC_NO_PATCHPF"), /*pp16*/ !env_flag("DSVC_NO_PP16"), /*epi_f32*/ !env_flag("DSVC_NO_EPI_F32"),
-    /*shuffle_vec*/ !env_flag("DSVC_NO_SHUFFLE_VEC"), /*head*/ getenv("DSVC_HEAD") ? atoi(getenv("DSVC_HEAD")) : !env_flag("DSVC_NO_HEAD"), /*conv1x1_rows*/ !env_flag("DSVC_NO_1X1_ROWS"), /*small_pf*/ !env_flag("DSVC_NO_SMALL_PF"), /*pps*/ !env_flag("DSVC_NO_PPS"), /*pps_f32*/ !env_flag("DSVC_NO_PPS_F32"), /*conv1x1_f32*/ !env_flag("DSVC_NO_1X1_F32"), /*head_f32*/ !env_flag("DSVC_NO_HEAD_F32"), /*skip_zero_k*/ !env_flag("DSVC_NO_SKIP_ZERO_K"), /*pp_qc*/ env_flag("DSVC_PP_QC"), /*pp_mix*/ !env_flag("DSVC_NO_PP_MIX")};
+    /*shuffle_vec*/ !env_flag("DSVC_NO_SHUFFLE_VEC"), /*head*/ getenv("DSVC_HEAD") ? atoi(getenv("DSVC_HEAD")) : !env_flag("DSVC_NO_HEAD"), /*conv1x1_rows*/ !env_flag("DSVC_NO_1X1_ROWS"), /*small_pf*/ !env_flag("DSVC_NO_SMALL_PF"), /*pps*/ !env_flag("DSVC_NO_PPS"), /*pps_f32*/ !env_flag("DSVC_NO_PPS_F32"), /*conv1x1_f32*/ !env_flag("DSVC_NO_1X1_F32"), /*head_f32*/ !env_flag("DSVC_NO_HEAD_F32"), /*skip_zero_k*/ !env_flag("DSVC_NO_SKIP_ZERO_K"), /*pp_qc*/ env_flag("DSVC_PP_QC"), /*pp_mix*/ !env_flag("DSVC_NO_PP_MIX"), /*pps_oneseg*/ !env_flag("DSVC_NO_PPS_ONESEG")};
 
 extern "C" int dsvc_set_option(const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
@@ -34,7 +34,7 @@ extern "C" int dsvc_set_option(const char* key, int value) {
         {"ws_waves4", &g_dsvc_opt.ws_waves4}, {"ws_direct_store", &g_dsvc_opt.ws_direct_store},
         {"tall_min_tiles", &g_dsvc_opt.tall_min_tiles}, {"reg_epilogue", &g_dsvc_opt.reg_epilogue},
         {"patch_prefetch", &g_dsvc_opt.patch_prefetch}, {"pp16", &g_dsvc_opt.pp16}, {"epi_f32", &g_dsvc_opt.epi_f32},
-        {"shuffle_vec", &g_dsvc_opt.shuffle_vec}, {"head", &g_dsvc_opt.head}, {"conv1x1_rows", &g_dsvc_opt.conv1x1_rows}, {"small_pf", &g_dsvc_opt.small_pf}, {"pps", &g_dsvc_opt.pps}, {"pps_f32", &g_dsvc_opt.pps_f32}, {"conv1x1_f32", &g_dsvc_opt.conv1x1_f32}, {"head_f32", &g_dsvc_opt.head_f32}, {"skip_zero_k", &g_dsvc_opt.skip_zero_k}, {"pp_qc", &g_dsvc_opt.pp_qc}, {"pp_mix", &g_dsvc_opt.pp_mix}};
+        {"shuffle_vec", &g_dsvc_opt.shuffle_vec}, {"head", &g_dsvc_opt.head}, {"conv1x1_rows", &g_dsvc_opt.conv1x1_rows}, {"small_pf", &g_dsvc_opt.small_pf}, {"pps", &g_dsvc_opt.pps}, {"pps_f32", &g_dsvc_opt.pps_f32}, {"conv1x1_f32", &g_dsvc_opt.conv1x1_f32}, {"head_f32", &g_dsvc_opt.head_f32}, {"skip_zero_k", &g_dsvc_opt.skip_zero_k}, {"pp_qc", &g_dsvc_opt.pp_qc}, {"pp_mix", &g_dsvc_opt.pp_mix}, {"pps_oneseg", &g_dsvc_opt.pps_oneseg}};
     for (auto& e : tab)
         if (key && strcmp(key, e.k) == 0) { const int old = *e.v; *e.v = value; return old; }
     dsvc_set_error("dsvc_set_option: unknown key '%s'", key ? key : "(null)");
