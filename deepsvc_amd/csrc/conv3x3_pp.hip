@@ -101,7 +101,7 @@ constexpr bool POST_IN_M1 = PP_POST_IN_M1 != 0;
 #endif
 // STORES keep the tile offset in the VECTOR offset (one v_add per store).  With the tile offset in the scalar-offset operand (a register)
 // the frame was no longer reproducible: decoded frames differed from run to run by up to 1.0 in millions of elements -- while every launch
-// in isolation, and every synchronised launch inside the frame, was bit-exact (tools/dbg/determinism.py; round 5).  Bisected to exactly
+// in isolation, and every synchronised launch inside the frame, was bit-exact (tools/frame_determinism.py; round 5).  Bisected to exactly
 // this: residual LOADS with a register scalar offset are fine, wide STORES are not.  The generated code issues
 //     buffer_store_dwordx4 v[52:55], v56, s[16:19], s4 offen
 //     v_or_b32 v52, ...                      <- overwrites the store's first data register in the next issue slot
@@ -293,11 +293,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     auto load_chunk = [&](const TileOrg& t, const int ch, uint4 (&pf)[PP_PFV]) {   // ch: a literal at every call site
         const int base_pix = (t.b * H + t.oy0 - 1) * W + t.ox0 - 1;        // scalar; >= -(W + 1): the guard makes the byte offset non-negative
         const unsigned so = (unsigned)(base_pix * (int)ldb_c[ch]) + sbase_c[ch];
-#ifdef PP_FORCE_EDGE
-        const bool interior = false;
-#else
         const bool interior = t.oy0 >= 1 && t.oy0 + PP_TH + 1 <= H && t.ox0 >= 1 && t.ox0 + PP_PW - 1 <= W;   // wave-uniform
-#endif
         unsigned dm[PP_PFV];
 #pragma unroll
         for (int j = 0; j < PP_PFV; ++j) dm[j] = 0u;
@@ -445,11 +441,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
     const unsigned evo_out = (unsigned)px_lane * ldo2 + piece_b, evo_r1 = (unsigned)px_lane * ld12 + piece_b, evo_r2 = (unsigned)px_lane * ld22 + piece_b;
     struct EpiRows { unsigned spix[2 * MTW], dm[2 * MTW]; };
     auto epi_rows = [&](const TileOrg& t, bool valid, EpiRows& er) {
-#ifdef PP_FORCE_EDGE
-        const bool interior = false;
-#else
         const bool interior = valid && t.oy0 + PP_TH <= p.Ho && t.ox0 + 32 <= p.Wo;          // wave-uniform
-#endif
 #pragma unroll
         for (int e = 0; e < 2 * MTW; ++e) {
             const int oy = t.oy0 + wg * MTW + (e >> 1);                                         // scalar
@@ -918,13 +910,6 @@ int dsvc_conv3x3_pp_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     const int ntiles = p.B * p.tiles_x * p.tiles_y;
     if ((int64_t)p.B * p.H * p.W >= (1 << 24)) return 1;   // pixel indices go through the 24-bit multiplier
     if (ntiles < 1024) return 1;           // small images: the generic kernel's finer tiling fills the chip better
-#ifdef DSVC_PP_DBG_SKIP                    // debug build: DSVC_PP_SKIP=<bits> hands a class of launches back to the other kernels (1 head, 2 fused tail, 4 one-chunk, 8 residual, 16 the rest)
-    {
-        static const int skip = getenv("DSVC_PP_SKIP") ? atoi(getenv("DSVC_PP_SKIP")) : 0;
-        const int cls = d->Cout <= 8 ? 1 : d->post_weight ? 2 : p.nchunks == 1 ? 4 : d->res1 ? 8 : 16;
-        if (skip & cls) return 1;
-    }
-#endif
     if (d->post_weight) {                  // fused ResBottleneck tail: conv3x3 -> act -> conv1x1 -> + residual
         float a_slope;
         if (p.nchunks != 2 || d->Cout != 64 || d->pre_act != DSVC_ACT_NONE || d->res2 || !slope_of(d->act, d->slope, &a_slope)) return 1;
