@@ -312,6 +312,31 @@ def test_gop_lanes_match_sequential_coding():
         ops.set_precision("fp32")
 
 
+def test_gop_lanes_match_sequential_coding_at_1080p():
+    """The same at 1088x1920, where the large-image kernels run (two-group 3x3 family, streamed weights, pointwise rows) and two lanes keep the
+    memory pipeline busy: rates and PSNR of every frame must equal sequential coding bit for bit.  This is the regime in which round 5's wide-store
+    hazard showed (csrc/conv3x3_pp.hip, PP_EPI_ST_SOFF): isolated launches exact, frames irreproducible under load."""
+    from deepsvc_amd import harness, ops, synth
+    ops.set_precision("f16")
+    try:
+        gops = []
+        for u in range(2):
+            frames = [f.to(DEV) for f in synth.make_frames(1080, 1920, 3, seed=300 + u)]
+            sms = [None] + [synth.make_sm_fea(1088, 1920, t, seed=300 + u).to(DEV) for t in (1, 2)]
+            gops.append((frames, sms))
+        models = []
+        for _ in range(2):
+            m = synth.make_model("W0"); m.update(force=True); models.append(m.to(DEV))
+        seq = [row for u, (fr, sm) in enumerate(gops) for row in harness.code_gop(models[0], fr, sm, unit=u, sync=torch.cuda.synchronize)]
+        for rep in range(2):
+            par = harness.code_gops_in_lanes(models, gops, torch.device(DEV))
+            assert len(par) == len(seq) == 4
+            for a, b in zip(seq, par):
+                assert a[:7] == b[:7], (rep, a[:7], b[:7])
+    finally:
+        ops.set_precision("fp32")
+
+
 def test_gop_lanes_with_a_lone_key_frame_gop():
     """a lane whose FIRST unit is a lone key frame (the tail GOP of a sequence: nothing to code) used to reach
     DeepSVC.warm_up with an empty frame list (ZeroDivisionError).  The harness now warms such a lane on another GOP's P-frames, and
