@@ -836,7 +836,7 @@ __global__ void __launch_bounds__(512, M16 ? 1 : PP_MIN_BLOCKS) conv3x3_pp_kerne
 
 template <int NT, int NCH, bool HEAD, bool PRE, bool ACT, bool HAS_R1, bool HAS_R2, bool POST = false, bool M16 = false, bool QC = false, bool RMIX = false>
 int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, float pre_slope) {
-#ifdef DSVC_PP_QC_VARIANT                       // measured slower (profiles/r05_pp_epilogue_experiments.txt): only in the variant build of tools/bench_pp_qc.py
+#ifdef DSVC_PP_QC_VARIANT                       // measured slower (profiles/r05_pp_epilogue_experiments.txt): only in the variant build described in tools/bench_pp_opt.py
     if constexpr (!QC && !HEAD) {               // option "pp_qc": quad-contiguous epilogue (see the kernel's header comment)
         if (g_dsvc_opt.pp_qc) return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, M16, true, RMIX>(st, p, ntiles, act_slope, pre_slope);
     }

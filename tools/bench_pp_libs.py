@@ -1,6 +1,6 @@
 """Same-box A/B of two BUILDS of the library on the two-group 3x3 kernel's variants at 1088x1920 (f16): each build runs in its own child
 process (DSVC_LIB=...), the children alternate over the rounds, best-of-rounds per variant is printed side by side.
-    python tools/bench_pp_libs.py deepsvc_amd/lib/libdsvc_prev.so deepsvc_amd/lib/libdsvc.so [--rounds 3]"""
+    python tools/bench_pp_libs.py deepsvc_amd/lib/libdsvc_<variant>.so deepsvc_amd/lib/libdsvc.so [--rounds 3]   (variants: python -m deepsvc_amd.build --variant NAME -DFOO=...)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
