@@ -848,6 +848,9 @@ int launch_pp(hipStream_t st, const ConvParams& p, int ntiles, float act_slope, 
         // option "pp16": 0 = 32x32x16 everywhere, 2 = 16x16x32 everywhere but the narrow heads, 1 (default) = where it measured faster
         // on the same box (tools/bench_pp16.py, 1088x1920, three interleaved rounds): one residual 187 -> 179 us, fused 1x1 tail
         // 212 -> 202 us; slower or equal elsewhere (plain 152 -> 153, pre + act 165 -> 174, two residuals 235 -> 254, 64 -> 32 99 -> 103)
+        // [r5] re-checked on the round-5 kernels: isolated, the one-residual variant is now faster on 32x32x16 (172.8 vs 177.6 us, tools/bench_pp16.py),
+        // but INSIDE the frame the 16x16x32 shape still wins (three alternating bench.py --lanes 1 runs per build on one box: dominant-conv
+        // average 0.1775 vs 0.1787 ms, 27.9 vs 27.8 fps): the policy stays
         const bool faster16 = NCH == 2 && NT == 2 && !PRE && HAS_R1 && !HAS_R2;
         if (g_dsvc_opt.pp16 == 2 || (g_dsvc_opt.pp16 == 1 && faster16))
             return launch_pp<NT, NCH, HEAD, PRE, ACT, HAS_R1, HAS_R2, POST, true, QC, RMIX>(st, p, ntiles, act_slope, pre_slope);
