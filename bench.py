@@ -292,6 +292,8 @@ def main():
     def timed(lanes, n):
         """Barrier + synchronize on both sides; every launch of the dominant conv shape inside is bracketed by HIP events on
         its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank], {residual operands: launches})"""
+        for L in lanes:                      # one GOP in flight: motion decode chain beside the encoder's tail; several: on the lane's own stream
+            L["model"].single_stream = len(lanes) == 1
         ops.profile_begin(3, 1, 64, 64, H_pad, W_pad)        # HIP events around every launch of the dominant conv shape, recorded in the C library
         barrier()
         t0 = time.perf_counter()
