@@ -222,6 +222,9 @@ def main():
             im.coder = args.coder
             im = im.to(dev)
         seed = 1234 + rank * 16 + ln
+        # several GOP lanes: the motion decode chain stays on the lane's stream and NO extra stream is ever created for it (streams are
+        # mapped onto the process's 4 hardware queues when they are created: four idle extra streams alone cost the 4-lane leg 3-4 %)
+        m.single_stream = args.lanes == 1
         return {"model": m.to(dev), "imodel": im, "stream": torch.cuda.Stream(dev), "t": 0, "ref": None, "feature": None, "rows": [],
                 "id": ln, "frames": [f.to(dev) for f in synth.make_frames(h, w, GOP, seed=seed)],
                 "sm": [None] + [synth.make_sm_fea(H_pad, W_pad, t, seed=seed).to(dev) for t in range(1, GOP)]}
