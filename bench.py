@@ -222,9 +222,6 @@ def main():
             im.coder = args.coder
             im = im.to(dev)
         seed = 1234 + rank * 16 + ln
-        # several GOP lanes: the motion decode chain stays on the lane's stream and NO extra stream is ever created for it (streams are
-        # mapped onto the process's 4 hardware queues when they are created: four idle extra streams alone cost the 4-lane leg 3-4 %)
-        m.single_stream = args.lanes == 1
         return {"model": m.to(dev), "imodel": im, "stream": torch.cuda.Stream(dev), "t": 0, "ref": None, "feature": None, "rows": [],
                 "id": ln, "frames": [f.to(dev) for f in synth.make_frames(h, w, GOP, seed=seed)],
                 "sm": [None] + [synth.make_sm_fea(H_pad, W_pad, t, seed=seed).to(dev) for t in range(1, GOP)]}
@@ -295,8 +292,6 @@ def main():
     def timed(lanes, n):
         """Barrier + synchronize on both sides; every launch of the dominant conv shape inside is bracketed by HIP events on
         its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank], {residual operands: launches})"""
-        for L in lanes:                      # one GOP in flight: motion decode chain beside the encoder's tail; several: on the lane's own stream
-            L["model"].single_stream = len(lanes) == 1
         ops.profile_begin(3, 1, 64, 64, H_pad, W_pad)        # HIP events around every launch of the dominant conv shape, recorded in the C library
         barrier()
         t0 = time.perf_counter()

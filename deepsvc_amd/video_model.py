@@ -20,10 +20,12 @@ from .ops import Act, to_act
 
 F32 = torch.float32
 # The motion decode chain on its own high-priority stream, overlapping the encoder's tail when compress() / decompress() are called back to
-# back (test_video.py:342,349).  [r5] ON when this model instance is the only one coding on the GPU (`DeepSVC.single_stream`, the default:
-# the reference's own sequential loop): one lane 35.3 -> 34.85 ms per 1080p frame in f16, **168.4 -> 163.5 ms in fp32** (its 60 ms of encoder
-# tail hide the whole chain); OFF for the GOP lanes of harness.code_gops_in_lanes / bench.py (with four lanes it costs 7-9 %: 12 streams share
-# the process's 4 hardware queues).  DSVC_MV_STREAM=1 / DSVC_NO_MV_STREAM=1 force it either way.
+# back (test_video.py:342,349).  OPT-IN: `model.single_stream = True` on an instance, or DSVC_MV_STREAM=1 for all (DSVC_NO_MV_STREAM=1: none).
+# [r5] In a process that holds ONE model (three streams: main, residual side stream, this one) it is worth 35.3 -> 34.85 ms per 1080p frame in
+# f16 and **168.4 -> 163.5 ms in fp32** (whose 60 ms of encoder tail hide the whole chain; two alternating `bench.py --lanes 1` runs each).  It is
+# not the default because the gain depends on how HIP maps streams onto the process's 4 hardware queues: with four GOP lanes it costs 7-9 %,
+# four IDLE extra streams alone cost the 4-lane leg 3-4 %, and the same one-lane leg run inside bench.py's default process (8+ streams alive)
+# came out SLOWER with it (fp32 5.71 vs 6.03 fps).  A full GPU test run with it on everywhere passed (287 tests): it is safe, not predictable.
 _env = __import__("os").environ
 MV_STREAM = [True if _env.get("DSVC_MV_STREAM", "") != "" else (False if _env.get("DSVC_NO_MV_STREAM", "") != "" else None)]     # None: per instance
 HOST_TRACE = None          # tools/host_profile_1080p.py sets a list: (label, perf_counter) stamps of the host thread inside compress / decompress
@@ -39,9 +41,8 @@ _DECODE_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="dsvc-resdec
 
 
 class DeepSVC(nn.Module):
-    # True: this instance is the only one coding on its GPU (one GOP in flight) -> decompress() runs the motion decode chain on its own stream
-    # beside the encoder's tail; the multi-lane harness sets it False on its lane models (see MV_STREAM above)
-    single_stream = True
+    # True: decompress() runs the motion decode chain on its own stream beside the encoder's tail (opt-in: see MV_STREAM above)
+    single_stream = False
 
     def __init__(self):
         super().__init__()
@@ -295,7 +296,7 @@ class DeepSVC(nn.Module):
         # this frame has just been queued (test_video.py:342,349 calls them back to back) part of its latency hides under the encoder's
         # remaining kernels (tiny kernels only get CU slots at the boundaries of the large ones, so the chain advances one launch per
         # large kernel: measured 7.9 ms for the chain beside E2 against ~4.5 ms alone).
-        use_mvs = MV_STREAM[0] if MV_STREAM[0] is not None else bool(getattr(self, "single_stream", True))
+        use_mvs = MV_STREAM[0] if MV_STREAM[0] is not None else bool(getattr(self, "single_stream", False))
         mvs = main if not use_mvs else self.__dict__.setdefault("_mv_streams", {}).get(str(dev))
         if mvs is None:
             mvs = self.__dict__["_mv_streams"][str(dev)] = torch.cuda.Stream(dev, priority=-1)
