@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--coder", default="rans", choices=["rans", "rans_ms"],
                     help="range coder of the y strings: rans = the reference's format (default, the headline); rans_ms = the GPU-decodable multi-stream "
                          "coder, a LABELLED non-reference format (+3-4 %% bytes, no host round trips in the decode chain)")
+    ap.add_argument("--one-lane-mv-stream", type=int, default=int(os.environ.get("DSVC_BENCH_ONE_LANE_MV", "0")),
+                    help="1: the one-GOP-in-flight legs run the motion decode chain on its own stream (DeepSVC.single_stream); never the multi-lane legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="headline leg only (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=256)
@@ -292,6 +294,8 @@ def main():
     def timed(lanes, n):
         """Barrier + synchronize on both sides; every launch of the dominant conv shape inside is bracketed by HIP events on
         its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank], {residual operands: launches})"""
+        for L in lanes:
+            L["model"].single_stream = bool(args.one_lane_mv_stream) and len(lanes) == 1
         ops.profile_begin(3, 1, 64, 64, H_pad, W_pad)        # HIP events around every launch of the dominant conv shape, recorded in the C library
         barrier()
         t0 = time.perf_counter()
