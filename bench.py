@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=4, help="independent GOP pipelines in flight per GPU (1 = strictly sequential frames)")
+    ap.add_argument("--lanes", type=int, default=6, help="independent GOP pipelines in flight per GPU (1 = strictly sequential frames)")
     ap.add_argument("--precision", default=os.environ.get("DSVC_PRECISION", "f16"), choices=["fp32", "f16"])
     ap.add_argument("--size", default="1080x1920")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3], help="BASELINE.json configs[1] (GOP=7, key frame given) or configs[2] (GOP=12, I-frame codec)")
@@ -273,6 +273,8 @@ def main():
         and frame programs (both variants) are in place -- everything a recording depends on belongs to the instance, so there is nothing to
         retry across lanes.  `n` (--warmup) further untimed steps per lane follow, one lane at a time."""
         for L in lanes:
+            L["model"].use_side_stream = len(lanes) == 1
+        for L in lanes:
             torch.cuda.set_device(dev)
             with torch.cuda.stream(L["stream"]):
                 if intra:
@@ -294,8 +296,9 @@ def main():
     def timed(lanes, n):
         """Barrier + synchronize on both sides; every launch of the dominant conv shape inside is bracketed by HIP events on
         its launch stream.  -> (max-over-ranks seconds, [ms per dominant launch on this rank], {residual operands: launches})"""
-        for L in lanes:
+        for L in lanes:                      # GOP lanes: one stream per lane; one GOP in flight: residual chain on its side stream
             L["model"].single_stream = bool(args.one_lane_mv_stream) and len(lanes) == 1
+            L["model"].use_side_stream = len(lanes) == 1
         ops.profile_begin(3, 1, 64, 64, H_pad, W_pad)        # HIP events around every launch of the dominant conv shape, recorded in the C library
         barrier()
         t0 = time.perf_counter()

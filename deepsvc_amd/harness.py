@@ -127,8 +127,9 @@ def code_gops_in_lanes(models, gops, device, metrics=True, i_models=None, overla
     import threading
     L = len(models)
     assert L >= 1 and (i_models is None or len(i_models) == L)
-    if L > 1:
-        for m in models:                     # several GOPs in flight: the motion decode chain stays on the lane's own stream (video_model.MV_STREAM)
+    for m in models:                         # several GOPs in flight: ONE stream per lane (video_model.DeepSVC.use_side_stream / single_stream)
+        m.use_side_stream = L == 1
+        if L > 1:
             m.single_stream = False
     streams = [torch.cuda.Stream(device) for _ in range(L)]
     mine = [[u for u in range(len(gops)) if u % L == ln] for ln in range(L)]

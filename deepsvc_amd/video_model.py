@@ -43,6 +43,9 @@ _DECODE_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="dsvc-resdec
 class DeepSVC(nn.Module):
     # True: decompress() runs the motion decode chain on its own stream beside the encoder's tail (opt-in: see MV_STREAM above)
     single_stream = False
+    # True (one GOP in flight): the residual decode chain runs on a side stream beside the prediction segment; the multi-lane harness sets it
+    # False on its lane models (one stream per lane: see decompress)
+    use_side_stream = True
 
     def __init__(self):
         super().__init__()
@@ -278,7 +281,11 @@ class DeepSVC(nn.Module):
         # the motion path until reconstruction: it runs on a worker thread / side stream so its idle gaps overlap the
         # motion decode chain and the MC / feature-extraction kernels of the main stream.
         main = torch.cuda.current_stream(dev)
-        side = self.__dict__.setdefault("_side_streams", {}).setdefault(str(dev), torch.cuda.Stream(dev))
+        # [r5] GOP lanes (use_side_stream = False): the chain runs on the lane's OWN stream (still from the worker thread, so the host decode
+        # overlaps this thread's launches): with several lanes the other lanes' kernels fill the gaps anyway, and every extra stream costs --
+        # HIP maps streams onto 4 hardware queues; one stream per lane instead of two: 4 lanes +2 %, 6 lanes +6 % (35.4-36.4 vs 33.7-33.9 fps)
+        use_side = bool(getattr(self, "use_side_stream", True)) and not _env.get("DSVC_NO_SIDE_STREAM")
+        side = main if not use_side else self.__dict__.setdefault("_side_streams", {}).setdefault(str(dev), torch.cuda.Stream(dev))
         side.wait_stream(main)
         res_done = torch.cuda.Event()
 
