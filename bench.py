@@ -14,7 +14,8 @@ whose key frame is coded by the I-frame codec `ICIP2020ResB` (configs[2]).  Synt
 collective); one metrics gather at the end.
 
 Prints ONE JSON line on rank 0 (contract in the task description): value = frames of all ranks / max-over-ranks time of the
-headline leg (f16 MFMA mode, `--lanes` GOP pipelines in flight per GPU).  Further legs of the same run, each barrier-bracketed
+headline leg (f16 MFMA mode, `--lanes` GOP pipelines in flight per GPU: default 6, ONE stream per lane since round 5 -- HIP maps streams onto
+4 hardware queues and a second stream per lane cost 6 % at six lanes).  Further legs of the same run, each barrier-bracketed
 and timed the same way, are reported inside the line:
   "lanes1"      the same mode with ONE GOP in flight (strictly sequential frames): fps, and the source of `roofline` -- HIP events
                 around every launch of the dominant conv shape in that region are the kernel's own durations (with several lanes

@@ -69,7 +69,7 @@ def by_shape(trace_csv, out_csv):
     return agg
 
 
-for run, name in (("l1", "f16_lanes1"), ("l4", "f16_lanes4"), ("f32", "fp32_lanes1")):
+for run, name in (("l1", "f16_lanes1"), ("l4", "f16_headline_lanes"), ("f32", "fp32_lanes1")):
     d = os.path.join(src, run)
     if not os.path.isdir(d):
         continue
