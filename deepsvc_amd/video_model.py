@@ -297,7 +297,10 @@ class DeepSVC(nn.Module):
                 res_done.record(side)
             return out
 
-        res_future = _DECODE_POOL.submit(decode_residual)
+        # GOP lanes (one stream per lane): the residual chain is issued by the lane thread itself once D1 is queued -- same rate as from a worker
+        # thread (36.3-36.7 vs 36.4-36.7 fps at six lanes, three rounds), one host thread fewer per lane; DSVC_RES_WORKER=1 brings the worker back
+        inline_res = (not use_side) and not _env.get("DSVC_RES_WORKER")
+        res_future = None if inline_res else _DECODE_POOL.submit(decode_residual)
         # The motion decode chain (host range decoder <-> tiny scan kernels, one sync per level) depends on the mv STRINGS only, not on
         # anything the GPU is still doing for the encoder: with MV_STREAM it runs on its own high-priority stream, so when compress() of
         # this frame has just been queued (test_video.py:342,349 calls them back to back) part of its latency hides under the encoder's
@@ -338,7 +341,7 @@ class DeepSVC(nn.Module):
 
         _, (warped, warp_fea, predict, predict_fea) = ops.run_segment(cache, ("D1", key), [ref, sm_fea] + opt, d1, arenas[0])
         _stamp("D1 queued")
-        res_coarse = res_future.result()
+        res_coarse = decode_residual() if inline_res else res_future.result()
         _stamp("res chain done")
         main.wait_event(res_done)
         res_coarse.buf.record_stream(main)
