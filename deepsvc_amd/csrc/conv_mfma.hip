@@ -31,6 +31,7 @@ int dsvc_conv1x1_f32_try(hipStream_t st, const dsvc_conv::ConvParams& p, const d
 int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv_head_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pps_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv_headtap_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 #ifdef DSVC_PHASE_PROBE
 // Build with DSVC_BUILD_DEFINES=-DDSVC_PHASE_PROBE (deepsvc_amd/build.py) to get per-phase shader-clock totals of wave 0 of
@@ -891,6 +892,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
         DSVC_REQUIRE(rc != 1, "conv2d: post_weight (fused 1x1) is not supported for this shape / type combination");
         if (rc == DSVC_OK) { dsvc_count(DSVC_CNT_PP); dsvc_count(DSVC_CNT_PP_POST); }
         return rc;
+    }
+    if (opt.specialised && opt.headtap) {   // 3x3 f16 heads with Cout <= 3 of large images: per-input-pixel (tap, output) GEMM on the matrix pipe + 9-point gather-sum
+        const int rc = dsvc_conv_headtap_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_HEADTAP);
+        if (rc != 1) return rc;
     }
     if (opt.specialised && opt.head) {      // narrow f16 output heads (Cout <= 4) of large images: dot products on the vector ALU
         const int rc = dsvc_conv_head_try((hipStream_t)stream, p, d);

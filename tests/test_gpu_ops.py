@@ -142,13 +142,15 @@ def test_narrow_head_dot_product_kernel(segs, cout, k, H, W, B, act, res_dtype, 
         ins = [_act(x, torch.float16) for x in xs]
         n0 = ops.get_counter("conv_head")
         prev = ops.set_option("head", 2)          # 2: also the shapes the dispatcher leaves to the MFMA kernels by default (64 -> 3, 64+64 -> 3)
-        got = m.run(ins, **kw)
-        assert ops.get_counter("conv_head") == n0 + 1, "the narrow-head kernel did not take this launch"
-        assert ops.set_option("head", 0) == 2
+        prev_tap = ops.set_option("headtap", 0)   # (round 5: the tap-GEMM kernel takes the 3x3 heads with Cout <= 3 first -- not the kernel under test here)
         try:
+            got = m.run(ins, **kw)
+            assert ops.get_counter("conv_head") == n0 + 1, "the narrow-head kernel did not take this launch"
+            assert ops.set_option("head", 0) == 2
             other = m.run(ins, **kw)
         finally:
             ops.set_option("head", prev)
+            ops.set_option("headtap", prev_tap)
         assert ops.get_counter("conv_head") == n0 + 1
         got, other = got.nchw().float().cpu(), other.nchw().float().cpu()
     finally:
@@ -160,6 +162,49 @@ def test_narrow_head_dot_product_kernel(segs, cout, k, H, W, B, act, res_dtype, 
         want = want + (res.to(torch.float16).float() if res_dtype == torch.float16 else res)
     close_f16(f"head {segs}->{cout} k{k}", got, want, out_f16=out_dtype == torch.float16)
     close_f16(f"head {segs}->{cout} k{k} vs MFMA kernels", got, other, out_f16=out_dtype == torch.float16, both_f16=out_dtype == torch.float16)
+
+
+@pytest.mark.parametrize("segs,cout,H,W,B,act,res_dtype,out_dtype", [
+    ((64,), 3, 250, 1100, 1, 0, None, torch.float32), ((64,), 3, 264, 1000, 1, 4, None, torch.float16), ((32,), 3, 256, 1056, 1, 2, None, torch.float32),
+    ((64,), 2, 250, 1090, 1, 0, torch.float32, torch.float32), ((64, 64), 3, 249, 1033, 1, 1, torch.float16, torch.float16), ((32, 32), 2, 130, 520, 1, 0, None, torch.float16),
+    ((64,), 1, 136, 250, 2, 3, torch.float16, torch.float32), ((64,), 3, 8, 32 * 256, 1, 0, None, torch.float32), ((32,), 3, 67, 300, 3, 5, torch.float32, torch.float16)])
+def test_narrow_head_tap_gemm_kernel(segs, cout, H, W, B, act, res_dtype, out_dtype):
+    """3x3 heads with Cout <= 3 of large f16 images as a per-INPUT-pixel GEMM over (tap, output) columns on the matrix pipe plus a 9-point
+    gather-sum of fp32 partial products in LDS (csrc/conv_headtap.hip): ragged tiles on both axes, zero padding on all four borders (a
+    one-tile-high image included), two input segments, batches, every activation, residual and output of either type -- against torch on
+    the f16-rounded operands, and against the kernels that took these launches before ("headtap" = 0) within the f16 summation-order tolerance."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(segs) + cout + H)
+    ops.set_precision("f16")
+    try:
+        m = Conv2d(sum(segs), cout, 3, 1, padding=1).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in segs]
+        res = torch.randn(B, cout, H, W) if res_dtype is not None else None
+        kw = dict(act=act, slope=0.1, out_dtype=out_dtype)
+        if res is not None:
+            kw["res1"] = _act(res, res_dtype)
+        ins = [_act(x, torch.float16) for x in xs]
+        n0 = ops.get_counter("conv_headtap")
+        prev = ops.set_option("headtap", 1)
+        try:
+            got = m.run(ins, **kw)
+            assert ops.get_counter("conv_headtap") == n0 + 1, "the tap-GEMM head kernel did not take this launch"
+            ops.set_option("headtap", 0)
+            other = m.run(ins, **kw)
+            assert ops.get_counter("conv_headtap") == n0 + 1
+        finally:
+            ops.set_option("headtap", prev)
+        got, other = got.nchw().float().cpu(), other.nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    x = torch.cat(xs, 1).to(torch.float16).float()
+    w = m.weight.detach().cpu().to(torch.float16).float()
+    want = _torch_act(F.conv2d(x, w, m.bias.detach().cpu(), padding=1), act, 0.1)
+    if res is not None:
+        want = want + (res.to(torch.float16).float() if res_dtype == torch.float16 else res)
+    close_f16(f"tap-GEMM head {segs}->{cout}", got, want, out_f16=out_dtype == torch.float16)
+    close_f16(f"tap-GEMM head {segs}->{cout} vs the other kernels", got, other, out_f16=out_dtype == torch.float16, both_f16=out_dtype == torch.float16)
 
 
 @pytest.mark.parametrize("compute", ["fp32", "f16"])

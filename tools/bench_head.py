@@ -30,9 +30,15 @@ for segs, cout, k, H, W, res in [((64,), 3, 3, 1088, 1920, False), ((32,), 3, 3,
     xs = [ops.to_act(torch.randn(1, c, H, W, device=dev), torch.float16) for c in segs]
     out = ops.new_act(1, H, W, cout, torch.float32, dev)
     kw = dict(res1=ops.to_act(torch.randn(1, cout, H, W, device=dev), torch.float32)) if res else {}
+    t_tap = timeit(lambda: m.run(xs, out, **kw))         # round 5: the tap-GEMM kernel (csrc/conv_headtap.hip) takes the 3x3 shapes first
+    tap_took = ops.get_counter("conv_headtap") > 0
+    ops.set_option("headtap", 0)
+    ops.set_option("head", 2)                            # 2: every shape the dot-product kernel covers
     t_head = timeit(lambda: m.run(xs, out, **kw))
     ops.set_option("head", 0)
     t_mfma = timeit(lambda: m.run(xs, out, **kw))
     ops.set_option("head", 1)
+    ops.set_option("headtap", 1)
     nbytes = sum(segs) * 2 * H * W
-    print(f"{k}x{k} {'+'.join(map(str, segs))}->{cout} @{H}x{W}{' + res' if res else ''}: dot-product kernel {t_head:7.1f} us ({nbytes / t_head / 1e6:5.2f} TB/s of input)   MFMA kernels {t_mfma:7.1f} us", flush=True)
+    tap = f"tap-GEMM kernel {t_tap:7.1f} us ({nbytes / t_tap / 1e6:5.2f} TB/s of input)   " if k == 3 and tap_took else ""
+    print(f"{k}x{k} {'+'.join(map(str, segs))}->{cout} @{H}x{W}{' + res' if res else ''}: {tap}dot-product kernel {t_head:7.1f} us ({nbytes / t_head / 1e6:5.2f} TB/s of input)   MFMA kernels {t_mfma:7.1f} us", flush=True)
