@@ -32,6 +32,7 @@ int dsvc_conv3x3_pp_try(hipStream_t st, const dsvc_conv::ConvParams& p, const ds
 int dsvc_conv_head_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv3x3_pps_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv_headtap_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv_cin8_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 #ifdef DSVC_PHASE_PROBE
 // Build with DSVC_BUILD_DEFINES=-DDSVC_PHASE_PROBE (deepsvc_amd/build.py) to get per-phase shader-clock totals of wave 0 of
@@ -896,6 +897,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     if (opt.specialised && opt.headtap) {   // 3x3 f16 heads with Cout <= 3 of large images: per-input-pixel (tap, output) GEMM on the matrix pipe + 9-point gather-sum
         const int rc = dsvc_conv_headtap_try((hipStream_t)stream, p, d);
         if (rc == DSVC_OK) dsvc_count(DSVC_CNT_HEADTAP);
+        if (rc != 1) return rc;
+    }
+    if (opt.specialised && opt.cin8) {      // f16 3x3 / 7x7 convs over one 8-channel input: the x-taps of a kernel row packed into the MFMA's K axis
+        const int rc = dsvc_conv_cin8_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_CIN8);
         if (rc != 1) return rc;
     }
     if (opt.specialised && opt.head) {      // narrow f16 output heads (Cout <= 4) of large images: dot products on the vector ALU

@@ -207,6 +207,43 @@ def test_narrow_head_tap_gemm_kernel(segs, cout, H, W, B, act, res_dtype, out_dt
     close_f16(f"tap-GEMM head {segs}->{cout} vs the other kernels", got, other, out_f16=out_dtype == torch.float16, both_f16=out_dtype == torch.float16)
 
 
+@pytest.mark.parametrize("split,cout,k,H,W,B,act", [
+    ((8,), 32, 7, 70, 250, 1, 1), ((3, 3, 2), 32, 7, 136, 240, 1, 1), ((3, 3, 2), 32, 7, 33, 130, 3, 2), ((8,), 32, 7, 8, 32 * 70, 1, 0),
+    ((3,), 64, 3, 120, 200, 1, 0), ((8,), 64, 3, 65, 129, 2, 1), ((8,), 32, 3, 128, 130, 1, 2), ((3, 2), 64, 3, 41, 400, 1, 0)])
+def test_cin8_conv_kernel(split, cout, k, H, W, B, act):
+    """f16 3x3 / 7x7 convs over ONE 8-channel input with the x-taps of a kernel row packed into the MFMA's K axis (csrc/conv_cin8.hip):
+    ME_Spynet's first conv over cat(ref, warped, flow) and the 3x3 convs over a frame padded to 8 channels, both as the frame issues them
+    (small fp32 inputs merged into one zero-padded f16 buffer) and over a plain 8-channel f16 tensor; ragged tiles on both axes, all four
+    borders, batches -- against torch on the f16-rounded operands, and against the kernels that took these launches before ("cin8" = 0)."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(sum(split) + cout + k + H)
+    ops.set_precision("f16")
+    try:
+        m = Conv2d(sum(split), cout, k, 1, padding=k // 2).to(DEV)
+        xs = [torch.randn(B, c, H, W) for c in split]
+        ins = [_act(x, torch.float16 if len(split) == 1 and split[0] == 8 else torch.float32) for x in xs]
+        kw = dict(act=act, slope=0.1, out_dtype=torch.float16)
+        n0 = ops.get_counter("conv_cin8")
+        prev = ops.set_option("cin8", 1)
+        try:
+            got = m.run(ins, **kw)
+            assert ops.get_counter("conv_cin8") == n0 + 1, "the 8-channel-input kernel did not take this launch"
+            ops.set_option("cin8", 0)
+            other = m.run(ins, **kw)
+            assert ops.get_counter("conv_cin8") == n0 + 1
+        finally:
+            ops.set_option("cin8", prev)
+        got, other = got.nchw().float().cpu(), other.nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    x = torch.cat(xs, 1).to(torch.float16).float()
+    w = m.weight.detach().cpu().to(torch.float16).float()
+    want = _torch_act(F.conv2d(x, w, m.bias.detach().cpu(), padding=k // 2), act, 0.1)
+    close_f16(f"cin8 {split}->{cout} k{k}", got, want, out_f16=True)
+    close_f16(f"cin8 {split}->{cout} k{k} vs the other kernels", got, other, out_f16=True, both_f16=True)
+
+
 @pytest.mark.parametrize("compute", ["fp32", "f16"])
 @pytest.mark.parametrize("cin,cq,k,H,W,act,with_res", [(64, 64, 3, 13, 37, 0, False), (96, 96, 3, 9, 33, 2, True), (64, 32, 1, 17, 41, 0, False),
                                                        (128, 64, 1, 8, 32, 1, True), (32, 4, 3, 5, 9, 0, True), (64, 64, 3, 70, 130, 0, False)])
