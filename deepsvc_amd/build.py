@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libdsvc.so")
-SOURCES = ["conv_mfma.hip", "conv3x3_ws.hip", "conv3x3_pp.hip", "conv3x3_pps.hip", "conv_head.hip", "conv_headtap.hip", "conv_cin8.hip", "conv_head_f32.hip", "conv1x1.hip", "conv1x1_f32.hip", "pointwise.hip", "msssim.hip", "entropy.hip", "rans_ms.hip", "rans_host.cpp", "host_misc.cpp", "pframe_program.cpp"]
+SOURCES = ["conv_mfma.hip", "conv3x3_ws.hip", "conv3x3_pp.hip", "conv3x3_pps.hip", "conv_head.hip", "conv_headtap.hip", "conv_cin8.hip", "conv7x7_rr.hip", "conv_head_f32.hip", "conv1x1.hip", "conv1x1_f32.hip", "pointwise.hip", "msssim.hip", "entropy.hip", "rans_ms.hip", "rans_host.cpp", "host_misc.cpp", "pframe_program.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "dsvc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("DSVC_BUILD_DEFINES", "").split()
 

@@ -39,12 +39,12 @@ void dsvc_set_error(const char* fmt, ...);
 #endif
 // ---- kernel-selection switches of dsvc_conv2d (dsvc_set_option, host_misc.cpp) ------------------
 struct DsvcOptions {
-    int specialised, pp, ws, conv1x1, ws_waves4, ws_direct_store, tall_min_tiles, reg_epilogue, patch_prefetch, pp16, epi_f32, shuffle_vec, head, conv1x1_rows, small_pf, pps, pps_f32, conv1x1_f32, head_f32, skip_zero_k, pp_qc, pp_mix, pps_oneseg, headtap, cin8;
+    int specialised, pp, ws, conv1x1, ws_waves4, ws_direct_store, tall_min_tiles, reg_epilogue, patch_prefetch, pp16, epi_f32, shuffle_vec, head, conv1x1_rows, small_pf, pps, pps_f32, conv1x1_f32, head_f32, skip_zero_k, pp_qc, pp_mix, pps_oneseg, headtap, cin8, rr7;
 };
 extern DsvcOptions g_dsvc_opt;
 
 // ---- launch counters (dsvc_get_counter, host_misc.cpp): which conv kernel family took a launch ----------------
-enum { DSVC_CNT_GENERIC = 0, DSVC_CNT_PP, DSVC_CNT_WS, DSVC_CNT_CONV1X1, DSVC_CNT_PP_POST, DSVC_CNT_HEAD, DSVC_CNT_PPS, DSVC_CNT_HEADTAP, DSVC_CNT_CIN8, DSVC_CNT_N };
+enum { DSVC_CNT_GENERIC = 0, DSVC_CNT_PP, DSVC_CNT_WS, DSVC_CNT_CONV1X1, DSVC_CNT_PP_POST, DSVC_CNT_HEAD, DSVC_CNT_PPS, DSVC_CNT_HEADTAP, DSVC_CNT_CIN8, DSVC_CNT_RR7, DSVC_CNT_N };
 extern long long g_dsvc_counters[DSVC_CNT_N];
 static inline void dsvc_count(int which) { __atomic_fetch_add(&g_dsvc_counters[which], 1, __ATOMIC_RELAXED); }
 

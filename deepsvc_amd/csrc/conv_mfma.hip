@@ -33,6 +33,7 @@ int dsvc_conv_head_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsv
 int dsvc_conv3x3_pps_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv_headtap_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 int dsvc_conv_cin8_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
+int dsvc_conv7x7_rr_try(hipStream_t st, const dsvc_conv::ConvParams& p, const dsvc_conv_desc* d);
 
 #ifdef DSVC_PHASE_PROBE
 // Build with DSVC_BUILD_DEFINES=-DDSVC_PHASE_PROBE (deepsvc_amd/build.py) to get per-phase shader-clock totals of wave 0 of
@@ -902,6 +903,11 @@ static int conv2d_impl(void* stream, const dsvc_conv_desc* d) {
     if (opt.specialised && opt.cin8) {      // f16 3x3 / 7x7 convs over one 8-channel input: the x-taps of a kernel row packed into the MFMA's K axis
         const int rc = dsvc_conv_cin8_try((hipStream_t)stream, p, d);
         if (rc == DSVC_OK) dsvc_count(DSVC_CNT_CIN8);
+        if (rc != 1) return rc;
+    }
+    if (opt.specialised && opt.rr7) {       // f16 7x7 convs 32 -> 16 / 32 / 64 and 64 -> 32: four output rows per wave, pixel fragments reused across kernel rows in registers
+        const int rc = dsvc_conv7x7_rr_try((hipStream_t)stream, p, d);
+        if (rc == DSVC_OK) dsvc_count(DSVC_CNT_RR7);
         if (rc != 1) return rc;
     }
     if (opt.specialised && opt.head) {      // narrow f16 output heads (Cout <= 4) of large images: dot products on the vector ALU

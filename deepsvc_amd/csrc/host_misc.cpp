@@ -25,7 +25,7 @@ DsvcOptions g_dsvc_opt = {
     /*ws_waves4*/ env_flag("DSVC_WS_WAVES4"), /*ws_direct_store*/ env_flag("DSVC_WS_DIRECT"),
     /*tall_min_tiles*/ getenv("DSVC_TALL_MIN_TILES") ? atoi(getenv("DSVC_TALL_MIN_TILES")) : 1024,
     /*reg_epilogue*/ !env_flag("DSVC_NO_REGEPI"), /*patch_prefetch*/ !env_flag("DSVC_NO_PATCHPF"), /*pp16*/ !env_flag("DSVC_NO_PP16"), /*epi_f32*/ !env_flag("DSVC_NO_EPI_F32"),
-    /*shuffle_vec*/ !env_flag("DSVC_NO_SHUFFLE_VEC"), /*head*/ getenv("DSVC_HEAD") ? atoi(getenv("DSVC_HEAD")) : !env_flag("DSVC_NO_HEAD"), /*conv1x1_rows*/ !env_flag("DSVC_NO_1X1_ROWS"), /*small_pf*/ !env_flag("DSVC_NO_SMALL_PF"), /*pps*/ !env_flag("DSVC_NO_PPS"), /*pps_f32*/ !env_flag("DSVC_NO_PPS_F32"), /*conv1x1_f32*/ !env_flag("DSVC_NO_1X1_F32"), /*head_f32*/ !env_flag("DSVC_NO_HEAD_F32"), /*skip_zero_k*/ !env_flag("DSVC_NO_SKIP_ZERO_K"), /*pp_qc*/ env_flag("DSVC_PP_QC"), /*pp_mix*/ !env_flag("DSVC_NO_PP_MIX"), /*pps_oneseg*/ !env_flag("DSVC_NO_PPS_ONESEG"), /*headtap*/ !env_flag("DSVC_NO_HEADTAP"), /*cin8*/ !env_flag("DSVC_NO_CIN8")};
+    /*shuffle_vec*/ !env_flag("DSVC_NO_SHUFFLE_VEC"), /*head*/ getenv("DSVC_HEAD") ? atoi(getenv("DSVC_HEAD")) : !env_flag("DSVC_NO_HEAD"), /*conv1x1_rows*/ !env_flag("DSVC_NO_1X1_ROWS"), /*small_pf*/ !env_flag("DSVC_NO_SMALL_PF"), /*pps*/ !env_flag("DSVC_NO_PPS"), /*pps_f32*/ !env_flag("DSVC_NO_PPS_F32"), /*conv1x1_f32*/ !env_flag("DSVC_NO_1X1_F32"), /*head_f32*/ !env_flag("DSVC_NO_HEAD_F32"), /*skip_zero_k*/ !env_flag("DSVC_NO_SKIP_ZERO_K"), /*pp_qc*/ env_flag("DSVC_PP_QC"), /*pp_mix*/ !env_flag("DSVC_NO_PP_MIX"), /*pps_oneseg*/ !env_flag("DSVC_NO_PPS_ONESEG"), /*headtap*/ !env_flag("DSVC_NO_HEADTAP"), /*cin8*/ !env_flag("DSVC_NO_CIN8"), /*rr7*/ !env_flag("DSVC_NO_RR7")};
 
 extern "C" int dsvc_set_option(const char* key, int value) {
     struct { const char* k; int* v; } tab[] = {
@@ -34,7 +34,7 @@ extern "C" int dsvc_set_option(const char* key, int value) {
         {"ws_waves4", &g_dsvc_opt.ws_waves4}, {"ws_direct_store", &g_dsvc_opt.ws_direct_store},
         {"tall_min_tiles", &g_dsvc_opt.tall_min_tiles}, {"reg_epilogue", &g_dsvc_opt.reg_epilogue},
         {"patch_prefetch", &g_dsvc_opt.patch_prefetch}, {"pp16", &g_dsvc_opt.pp16}, {"epi_f32", &g_dsvc_opt.epi_f32},
-        {"shuffle_vec", &g_dsvc_opt.shuffle_vec}, {"head", &g_dsvc_opt.head}, {"conv1x1_rows", &g_dsvc_opt.conv1x1_rows}, {"small_pf", &g_dsvc_opt.small_pf}, {"pps", &g_dsvc_opt.pps}, {"pps_f32", &g_dsvc_opt.pps_f32}, {"conv1x1_f32", &g_dsvc_opt.conv1x1_f32}, {"head_f32", &g_dsvc_opt.head_f32}, {"skip_zero_k", &g_dsvc_opt.skip_zero_k}, {"pp_qc", &g_dsvc_opt.pp_qc}, {"pp_mix", &g_dsvc_opt.pp_mix}, {"pps_oneseg", &g_dsvc_opt.pps_oneseg}, {"headtap", &g_dsvc_opt.headtap}, {"cin8", &g_dsvc_opt.cin8}};
+        {"shuffle_vec", &g_dsvc_opt.shuffle_vec}, {"head", &g_dsvc_opt.head}, {"conv1x1_rows", &g_dsvc_opt.conv1x1_rows}, {"small_pf", &g_dsvc_opt.small_pf}, {"pps", &g_dsvc_opt.pps}, {"pps_f32", &g_dsvc_opt.pps_f32}, {"conv1x1_f32", &g_dsvc_opt.conv1x1_f32}, {"head_f32", &g_dsvc_opt.head_f32}, {"skip_zero_k", &g_dsvc_opt.skip_zero_k}, {"pp_qc", &g_dsvc_opt.pp_qc}, {"pp_mix", &g_dsvc_opt.pp_mix}, {"pps_oneseg", &g_dsvc_opt.pps_oneseg}, {"headtap", &g_dsvc_opt.headtap}, {"cin8", &g_dsvc_opt.cin8}, {"rr7", &g_dsvc_opt.rr7}};
     for (auto& e : tab)
         if (key && strcmp(key, e.k) == 0) { const int old = *e.v; *e.v = value; return old; }
     dsvc_set_error("dsvc_set_option: unknown key '%s'", key ? key : "(null)");
@@ -46,7 +46,7 @@ extern long long g_dsvc_lut_overflow;      // rans_host.cpp
 extern "C" int64_t dsvc_get_counter(const char* key) {
     if (key && strcmp(key, "lut_registry_overflow") == 0) return (int64_t)__atomic_load_n(&g_dsvc_lut_overflow, __ATOMIC_RELAXED);
     struct { const char* k; int i; } tab[] = {{"conv_generic", DSVC_CNT_GENERIC}, {"conv3x3_pp", DSVC_CNT_PP}, {"conv3x3_ws", DSVC_CNT_WS},
-                                              {"conv1x1", DSVC_CNT_CONV1X1}, {"conv3x3_pp_fused_tail", DSVC_CNT_PP_POST}, {"conv_head", DSVC_CNT_HEAD}, {"conv3x3_pps", DSVC_CNT_PPS}, {"conv_headtap", DSVC_CNT_HEADTAP}, {"conv_cin8", DSVC_CNT_CIN8}};
+                                              {"conv1x1", DSVC_CNT_CONV1X1}, {"conv3x3_pp_fused_tail", DSVC_CNT_PP_POST}, {"conv_head", DSVC_CNT_HEAD}, {"conv3x3_pps", DSVC_CNT_PPS}, {"conv_headtap", DSVC_CNT_HEADTAP}, {"conv_cin8", DSVC_CNT_CIN8}, {"conv7x7_rr", DSVC_CNT_RR7}};
     for (auto& e : tab)
         if (key && strcmp(key, e.k) == 0) return (int64_t)__atomic_load_n(&g_dsvc_counters[e.i], __ATOMIC_RELAXED);
     dsvc_set_error("dsvc_get_counter: unknown key '%s'", key ? key : "(null)");

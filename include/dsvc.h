@@ -71,14 +71,17 @@ int dsvc_device_count(void);
  * channels on 256+ tiles run as a per-input-pixel GEMM over (tap, output) columns on the matrix pipe followed by a 9-point gather-sum,
  * csrc/conv_headtap.hip: tried before "head"; 0: "head" and the MFMA kernels decide), "cin8" (1: f16 3x3 -> 32 / 64 and 7x7 -> 32 stride-1 convs over ONE
  * segment of exactly 8 channels with contiguous 16-byte pixels, f16 output, no residual, activation none / ReLU / LeakyReLU, on 64+ tiles pack the
- * x-taps of a kernel row into the MFMA's K axis, csrc/conv_cin8.hip; 0: the other kernels pad each tap to a 32-channel chunk).  Defaults come from
+ * x-taps of a kernel row into the MFMA's K axis, csrc/conv_cin8.hip; 0: the other kernels pad each tap to a 32-channel chunk), "rr7" (1: f16 7x7
+ * stride-1 convs 32 -> 16 / 32 / 64 and 64 -> 32 over one segment, f16 output, no residual, activation none / ReLU / LeakyReLU, on 128+ tiles of
+ * 16x32 pixels: each wave owns four output rows and reuses a pixel fragment across the kernel rows in registers, weights straight from global
+ * memory, csrc/conv7x7_rr.hip; 0: the general kernel).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
- * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF, DSVC_NO_PPS, DSVC_NO_PPS_F32, DSVC_NO_1X1_F32, DSVC_NO_HEAD_F32, DSVC_NO_SKIP_ZERO_K, DSVC_NO_HEADTAP, DSVC_NO_CIN8).
+ * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF, DSVC_NO_PPS, DSVC_NO_PPS_F32, DSVC_NO_1X1_F32, DSVC_NO_HEAD_F32, DSVC_NO_SKIP_ZERO_K, DSVC_NO_HEADTAP, DSVC_NO_CIN8, DSVC_NO_RR7).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
  * fp32 mode; in f16 mode they agree within the f16 tolerance of the tests. */
 int dsvc_set_option(const char* key, int value);
 /* Diagnostic: how many dsvc_conv2d launches each kernel family has taken since the library was loaded (process-wide).
- * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head", "conv3x3_pps", "conv_headtap", "conv_cin8"; "lut_registry_overflow" (see dsvc_cdf_build_lut).  Tests use it to prove that the
+ * Keys: "conv_generic", "conv3x3_pp", "conv3x3_pp_fused_tail", "conv3x3_ws", "conv1x1", "conv_head", "conv3x3_pps", "conv_headtap", "conv_cin8", "conv7x7_rr"; "lut_registry_overflow" (see dsvc_cdf_build_lut).  Tests use it to prove that the
  * large-image kernels ran inside a frame that is checked against the reference.  Returns DSVC_E_ARG for an unknown key. */
 int64_t dsvc_get_counter(const char* key);
 /* Diagnostic: time every dsvc_conv2d launch of ONE shape (single-segment k x k conv, `stride`, C -> Cout channels on an H x W input) with

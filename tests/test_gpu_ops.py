@@ -244,6 +244,40 @@ def test_cin8_conv_kernel(split, cout, k, H, W, B, act):
     close_f16(f"cin8 {split}->{cout} k{k} vs the other kernels", got, other, out_f16=True, both_f16=True)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B,act", [(64, 32, 150, 450, 1, 1), (32, 64, 136, 480, 1, 1), (32, 16, 272, 250, 1, 1), (32, 32, 130, 250, 2, 2),
+                                                (64, 32, 16, 32 * 130, 1, 0), (32, 16, 67, 129, 7, 1)])
+def test_conv7x7_row_reuse_kernel(cin, cout, H, W, B, act):
+    """f16 7x7 convs 32 -> 16 / 32 / 64 and 64 -> 32 (ME_Spynet's inner convs, modules.py:127-131) with four output rows per wave, pixel
+    fragments reused across the kernel rows in registers and weights loaded straight from the packed buffer (csrc/conv7x7_rr.hip): ragged
+    tiles on both axes (a one-tile-high image included), all four borders, batches, two input chunks, two output passes, the 16-channel
+    output's half rows -- against torch on the f16-rounded operands, and against the general kernel ("rr7" = 0)."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    torch.manual_seed(cin + cout + H)
+    ops.set_precision("f16")
+    try:
+        m = Conv2d(cin, cout, 7, 1, padding=3).to(DEV)
+        x = torch.randn(B, cin, H, W)
+        kw = dict(act=act, slope=0.1, out_dtype=torch.float16)
+        n0 = ops.get_counter("conv7x7_rr")
+        prev = ops.set_option("rr7", 1)
+        try:
+            got = m.run([_act(x, torch.float16)], **kw)
+            assert ops.get_counter("conv7x7_rr") == n0 + 1, "the row-reuse 7x7 kernel did not take this launch"
+            ops.set_option("rr7", 0)
+            other = m.run([_act(x, torch.float16)], **kw)
+            assert ops.get_counter("conv7x7_rr") == n0 + 1
+        finally:
+            ops.set_option("rr7", prev)
+        got, other = got.nchw().float().cpu(), other.nchw().float().cpu()
+    finally:
+        ops.set_precision("fp32")
+    w = m.weight.detach().cpu().to(torch.float16).float()
+    want = _torch_act(F.conv2d(x.to(torch.float16).float(), w, m.bias.detach().cpu(), padding=3), act, 0.1)
+    close_f16(f"7x7 row reuse {cin}->{cout}", got, want, out_f16=True)
+    close_f16(f"7x7 row reuse {cin}->{cout} vs the general kernel", got, other, out_f16=True, both_f16=True)
+
+
 @pytest.mark.parametrize("compute", ["fp32", "f16"])
 @pytest.mark.parametrize("cin,cq,k,H,W,act,with_res", [(64, 64, 3, 13, 37, 0, False), (96, 96, 3, 9, 33, 2, True), (64, 32, 1, 17, 41, 0, False),
                                                        (128, 64, 1, 8, 32, 1, True), (32, 4, 3, 5, 9, 0, True), (64, 64, 3, 70, 130, 0, False)])
@@ -1230,6 +1264,7 @@ def test_pp_kernel_touches_nothing_outside_its_tensors():
     from deepsvc_amd.modules import Conv2d
     ops.set_precision("f16")
     h = torch.float16
+    prev_tap = ops.set_option("headtap", 0)        # the HEAD variant of the two-group kernel is under test here (the tap-GEMM kernel takes 64 -> 3 first)
     try:
         H, W = 256, 1024
         torch.manual_seed(0)
@@ -1261,6 +1296,57 @@ def test_pp_kernel_touches_nothing_outside_its_tensors():
             if odt == h:
                 mask[oo:oo + H * W * cout] = False
             assert bool(torch.isnan(big[mask]).all()), f"{name}: wrote outside its output tensor"
+    finally:
+        ops.set_option("headtap", prev_tap)
+        ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("name,counter,segs,cout,k,H,W", [
+    ("tap-GEMM head 64->3", "conv_headtap", (64,), 3, 3, 250, 1000), ("tap-GEMM head 64+64->3", "conv_headtap", (64, 64), 3, 3, 131, 520),
+    ("cin8 7x7 8->32", "conv_cin8", (8,), 32, 7, 130, 500), ("cin8 3x3 8->64", "conv_cin8", (8,), 64, 3, 129, 515),
+    ("row-reuse 7x7 64->32", "conv7x7_rr", (64,), 32, 7, 250, 500), ("row-reuse 7x7 32->64", "conv7x7_rr", (32,), 64, 7, 245, 505),
+    ("row-reuse 7x7 32->16", "conv7x7_rr", (32,), 16, 7, 250, 500)])
+def test_round5_kernels_touch_nothing_outside_their_tensors(name, counter, segs, cout, k, H, W):
+    """The persistent / halo-staging kernels of round 5's second half (csrc/conv_headtap.hip, conv_cin8.hip, conv7x7_rr.hip) mask every access
+    outside the picture themselves (bounds-checked buffer loads with an explicit out-of-range offset; whole-row stores of ragged tiles): inputs
+    and output are carved out of ONE buffer full of NaN with 4 M elements of NaN between them -- the result must equal the run on stand-alone
+    tensors bit for bit, contain no NaN, and leave every NaN around the tensors in place (ragged pictures: the last tile row / column is partial)."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    ops.set_precision("f16")
+    h = torch.float16
+    try:
+        torch.manual_seed(1)
+        conv = Conv2d(sum(segs), cout, k, 1, k // 2).to(DEV)
+        clean = [torch.randn((1, H, W, c), device=DEV).to(h) for c in segs]
+        odt = torch.float32 if cout <= 8 else h
+        before = ops.get_counter(counter)
+        ref = conv.run([ops.Act(x) for x in clean], out_dtype=odt, act=1).buf.clone()
+        assert ops.get_counter(counter) == before + 1, f"{name}: the kernel under test did not take this launch"
+        pad = 4 * 1024 * 1024
+        n_in = [H * W * c for c in segs]
+        big = torch.full((pad * (len(segs) + 2) + sum(n_in) + H * W * cout + 64,), float("nan"), device=DEV, dtype=h)
+        offs, o = [], pad
+        for n in n_in:
+            offs.append(o); o += n + pad
+        oo = o
+        xs = []
+        for off, c, xc in zip(offs, segs, clean):
+            v = big[off:off + H * W * c].view(1, H, W, c); v.copy_(xc); xs.append(ops.Act(v))
+        if odt == h:
+            out = conv.run(xs, ops.Act(big[oo:oo + H * W * cout].view(1, H, W, cout)), out_dtype=h, act=1).buf
+        else:
+            out = conv.run(xs, out_dtype=odt, act=1).buf
+        torch.cuda.synchronize()
+        assert ops.get_counter(counter) == before + 2
+        assert not bool(torch.isnan(out.float()).any()), f"{name}: NaN from outside the tensors reached the output"
+        assert torch.equal(out, ref), f"{name}: differs from the run on stand-alone tensors"
+        mask = torch.ones_like(big, dtype=torch.bool)
+        for off, n in zip(offs, n_in):
+            mask[off:off + n] = False
+        if odt == h:
+            mask[oo:oo + H * W * cout] = False
+        assert bool(torch.isnan(big[mask]).all()), f"{name}: wrote outside its output tensor"
     finally:
         ops.set_precision("fp32")
 
