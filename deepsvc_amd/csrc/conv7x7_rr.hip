@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256, 2) conv7x7_rr_kernel(const ConvParams p, 
                     const int py = pix / RR_PW, px = pix - py * RR_PW;
                     const int iy = oy0 - 3 + py, ix = ox0 - 3 + px;
                     const bool inb = vi < RR_NV && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    v[i] = buf_load16(rin, inb ? (unsigned)((b * p.H + iy) * p.W + ix) * ipitch + (unsigned)(kc * 64 + piece * 16) : OOB);
+                    v[i] = buf_load16(rin, (((unsigned)((b * p.H + iy) * p.W + ix) * ipitch + (unsigned)(kc * 64 + piece * 16)) & 0x7FFFFFFFu) | (inb ? 0u : OOB));
                 }
 #pragma unroll
                 for (int i = 0; i < RR_NLD; ++i) {
@@ -105,10 +105,16 @@ __global__ void __launch_bounds__(256, 2) conv7x7_rr_kernel(const ConvParams p, 
             if (pr - y >= 0 && pr - y < 7)                                                                                \
                 acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, BW[pr - y]), __builtin_bit_cast(h16x8, a), acc[y], 0, 0, 0); \
     }
+                // the refills are pinned where they are written: left to itself the scheduler sinks all fourteen loads to the end of the body, and
+                // the next iteration's first MFMA then waits for a whole L2 round trip (14 round trips per chunk)
                 RR_HALF(ba, 0)
+                __builtin_amdgcn_sched_barrier(0);
                 load_b(kc, kx + 1, 0, n, kx < 6, ba);
+                __builtin_amdgcn_sched_barrier(0);
                 RR_HALF(bb, 1)
+                __builtin_amdgcn_sched_barrier(0);
                 load_b(kc, kx + 1, 1, n, kx < 6, bb);
+                __builtin_amdgcn_sched_barrier(0);
 #undef RR_HALF
             }
         }

@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(256) conv_cin8_kernel(const ConvParams p, int 
             const int py = vi / PW, px = vi - py * PW;
             const int iy = oy0 - KS / 2 + py, ix = ox0 - KS / 2 + px;
             const bool inb = live && vi < NV && px < PW - 1 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            v[i] = buf_load16(rin, inb ? (unsigned)(((b * p.H + iy) * p.W + ix) * 16) : OOB);
+            // (offset | OOB, not a select: hipcc turns a select of offsets into exec-mask branches around each load and sinks them behind the MFMA phase)
+            v[i] = buf_load16(rin, ((unsigned)(((b * p.H + iy) * p.W + ix) * 16) & 0x7FFFFFFFu) | (inb ? 0u : OOB));
         }
     };
     uint4 v[NLD];
@@ -87,6 +88,7 @@ __global__ void __launch_bounds__(256) conv_cin8_kernel(const ConvParams p, int 
         }
         lds_barrier();                                         // (first pass: also the weights and the bias)
         issue(t + (int)gridDim.x, v);
+        __builtin_amdgcn_sched_barrier(0);                     // the prefetch is issued HERE: it has the whole MFMA phase to land
         f32x16 acc[2][NT];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
