@@ -154,6 +154,119 @@ __global__ void __launch_bounds__(256, 2) conv7x7_rr_kernel(const ConvParams p, 
     }
 }
 
+// ---- 32 -> 16: the same row-reuse walk on v_mfma_f32_16x16x32_f16 ----
+// A 32-row weight tile is half padding when the conv has 16 outputs.  On the 16x16x32 shape (A = 16 weight rows x 32 channels, B = 32 channels x 16
+// pixels, 16 cycles) ONE MFMA consumes a whole 32-channel tap for 16 pixels: 392 MFMAs of 16 cycles per wave and tile instead of 392 of 32.  Lane
+// (c, q) = (lane % 16, lane / 16) reads the 16 bytes of channels 8q .. 8q + 7 of its pixel / of weight row c, and ends up with channels 4q .. 4q + 3
+// of pixel c: one 8-byte store, 16 pixels x 32 B = 512 contiguous bytes per instruction -- no LDS in the epilogue.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256, 2) conv7x7_rr16_kernel(const ConvParams p, float act_slope) {
+    DSVC_F16_SAT();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    char* patch = smem;
+    int bid = blockIdx.x;
+    const int tx0 = bid % p.tiles_x; bid /= p.tiles_x;
+    const int ty0 = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int oy0 = ty0 * RR_TH, ox0 = tx0 * RR_TW;
+    const rsrc_t rin = make_rsrc(p.seg[0].ptr, p.seg[0].bytes);
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+    const rsrc_t rout = make_rsrc(p.out, p.out_bytes);
+    const unsigned ipitch = (unsigned)p.seg[0].ld * 2u, opitch = (unsigned)p.out_ld * 2u;
+    auto load_w = [&](int kx, uint4 (&w)[7]) {                // weight row (tap (ky, kx), output c), channels 8q .. 8q + 7
+        const unsigned base = (unsigned)((kx * p.Np + c) * 64 + q * 16);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) w[ky] = buf_load16(rw, base + (unsigned)(ky * 7 * p.Np * 64));
+    };
+    uint4 wa[7], wb[7];
+    load_w(0, wa);
+    {   // ---- stage the patch (as in conv7x7_rr_kernel) ----
+        uint4 v[RR_NLD];
+#pragma unroll
+        for (int i = 0; i < RR_NLD; ++i) {
+            const int vi = tid + 256 * i;
+            const int pix = vi >> 2, piece = vi & 3;
+            const int py = pix / RR_PW, px = pix - py * RR_PW;
+            const int iy = oy0 - 3 + py, ix = ox0 - 3 + px;
+            const bool inb = vi < RR_NV && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            v[i] = buf_load16(rin, (((unsigned)((b * p.H + iy) * p.W + ix) * ipitch + (unsigned)(piece * 16)) & 0x7FFFFFFFu) | (inb ? 0u : OOB));
+        }
+#pragma unroll
+        for (int i = 0; i < RR_NLD; ++i) {
+            const int vi = tid + 256 * i;
+            if (vi < RR_NV) *(uint4*)(patch + (vi >> 2) * RR_PITCH + (vi & 3) * 16) = v[i];
+        }
+        lds_barrier();
+    }
+    f32x4_t acc[4][2];
+    {
+        float bq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = (p.bias && 4 * q + j < p.Cout) ? p.bias[4 * q + j] : 0.f;      // accumulator row j = channel 4q + j
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[y][hf][j] = bq[j];
+    }
+    const char* arow = patch + ((4 * wave) * RR_PW + c) * RR_PITCH + q * 16;
+#define RR16_COL(W, KX)                                                                                                      \
+    _Pragma("unroll") for (int pr = 0; pr < 10; ++pr)                                                                        \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                                   \
+            const uint4 a = *(const uint4*)(arow + (pr * RR_PW + (KX) + 16 * hf) * RR_PITCH);                                \
+            _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                                    \
+                if (pr - y >= 0 && pr - y < 7)                                                                               \
+                    acc[y][hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, W[pr - y]), __builtin_bit_cast(h16x8, a), acc[y][hf], 0, 0, 0); \
+        }
+#pragma unroll 1
+    for (int kx = 0; kx < 6; kx += 2) {                        // columns kx (wa) and kx + 1 (wb); each refill is issued one column ahead
+        load_w(kx + 1, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        RR16_COL(wa, kx)
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(kx + 2, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        RR16_COL(wb, kx + 1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    RR16_COL(wa, 6)
+#undef RR16_COL
+    // ---- epilogue: lane (c, q) holds channels 4q .. 4q + 3 of pixel c of each 16-pixel half: activation, f16 pack, one 8-byte store ----
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const int oy = oy0 + 4 * wave + y;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int ox = ox0 + 16 * hf + c;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_fmed3f(acc[y][hf][j], acc[y][hf][j] * act_slope, __builtin_inff());
+            v2u_t ov;
+            ov.x = pk_h16(o[0], o[1]); ov.y = pk_h16(o[2], o[3]);
+            const bool ok = oy < p.Ho && ox < p.Wo;
+            __builtin_amdgcn_raw_buffer_store_b64(ov, rout, (((unsigned)((b * p.Ho + oy) * p.Wo + ox) * opitch + (unsigned)q * 8u) & 0x7FFFFFFFu) | (ok ? 0u : OOB), 0, 0);
+        }
+    }
+}
+
+int launch_rr16(hipStream_t st, const ConvParams& p, int ntiles, float act_slope) {
+    constexpr size_t lds = (size_t)RR_PH * RR_PW * RR_PITCH;       // 66.9 KB: two workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv7x7_rr16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { dsvc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return DSVC_E_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv7x7_rr16_kernel, dim3(ntiles), dim3(256), lds, st, p, act_slope);
+    DSVC_CHECK_LAUNCH("conv7x7_rr16_kernel");
+    return DSVC_OK;
+}
+
 template <int NCH, int COUT8>
 int launch_rr(hipStream_t st, const ConvParams& p, int ntiles, float act_slope) {
     constexpr size_t lds = (size_t)RR_PH * RR_PW * RR_PITCH + (size_t)4 * 32 * RR_TP;       // 66.9 + 10.2 KB: two workgroups per CU
@@ -194,5 +307,6 @@ int dsvc_conv7x7_rr_try(hipStream_t st, const ConvParams& p_in, const dsvc_conv_
     if (sg.C == 64) return launch_rr<2, 4>(st, p, (int)nt, act_slope);
     if (d->Cout == 64) return launch_rr<1, 8>(st, p, (int)nt, act_slope);
     if (d->Cout == 32) return launch_rr<1, 4>(st, p, (int)nt, act_slope);
-    return launch_rr<1, 2>(st, p, (int)nt, act_slope);
+    if (g_dsvc_opt.rr7 >= 2) return launch_rr<1, 2>(st, p, (int)nt, act_slope);       // (A/B: the 32-row-tile variant with half of its rows padding)
+    return launch_rr16(st, p, (int)nt, act_slope);
 }

@@ -74,7 +74,7 @@ int dsvc_device_count(void);
  * x-taps of a kernel row into the MFMA's K axis, csrc/conv_cin8.hip; 0: the other kernels pad each tap to a 32-channel chunk), "rr7" (1: f16 7x7
  * stride-1 convs 32 -> 16 / 32 / 64 and 64 -> 32 over one segment, f16 output, no residual, activation none / ReLU / LeakyReLU, on 128+ tiles of
  * 16x32 pixels: each wave owns four output rows and reuses a pixel fragment across the kernel rows in registers, weights straight from global
- * memory, csrc/conv7x7_rr.hip; 0: the general kernel).  Defaults come from
+ * memory, csrc/conv7x7_rr.hip -- 32 -> 16 on the 16x16x32 MFMA shape, without padded weight rows; 2: 32 -> 16 on the 32-row tile like the others (A/B); 0: the general kernel).  Defaults come from
  * the environment at load time (DSVC_NO_WS, DSVC_NO_PP, DSVC_WS_WAVES4, DSVC_WS_DIRECT,
  * DSVC_TALL_MIN_TILES, DSVC_NO_REGEPI, DSVC_NO_PATCHPF, DSVC_NO_PP16, DSVC_NO_EPI_F32, DSVC_NO_SHUFFLE_VEC, DSVC_NO_HEAD / DSVC_HEAD, DSVC_NO_1X1_ROWS, DSVC_NO_SMALL_PF, DSVC_NO_PPS, DSVC_NO_PPS_F32, DSVC_NO_1X1_F32, DSVC_NO_HEAD_F32, DSVC_NO_SKIP_ZERO_K, DSVC_NO_HEADTAP, DSVC_NO_CIN8, DSVC_NO_RR7).
  * Returns the previous value, or DSVC_E_ARG for an unknown key.  Results are identical whichever kernel runs in
