@@ -1351,6 +1351,55 @@ def test_round5_kernels_touch_nothing_outside_their_tensors(name, counter, segs,
         ops.set_precision("fp32")
 
 
+@pytest.mark.parametrize("name,counter,cin,cout,k,H,W", [
+    ("tap-GEMM head 64->3", "conv_headtap", 64, 3, 3, 130, 520), ("tap-GEMM head 32->2", "conv_headtap", 32, 2, 3, 140, 500),
+    ("cin8 7x7 8->32", "conv_cin8", 8, 32, 7, 90, 260), ("cin8 3x3 8->64", "conv_cin8", 8, 64, 3, 90, 260),
+    ("row-reuse 7x7 64->32", "conv7x7_rr", 64, 32, 7, 180, 400), ("row-reuse 7x7 32->64", "conv7x7_rr", 32, 64, 7, 180, 400),
+    ("row-reuse 7x7 32->16", "conv7x7_rr", 32, 16, 7, 180, 400)])
+def test_round5_kernels_on_channel_slices(name, counter, cin, cout, k, H, W):
+    """The same kernels through VIEWS, as the frame's virtual concatenations use them: the input is a channel slice of a wider buffer (pixel pitch
+    larger than its channel count; the 8-channel kernel needs contiguous pixels and takes a plain tensor), the output a channel slice of a wider
+    buffer pre-filled with 7 (and the head's residual another slice): results equal the run on plain tensors bit for bit, and the channels
+    beside the output slice keep their 7s -- the whole-row stores write exactly the slice's bytes of every pixel row."""
+    from deepsvc_amd import ops
+    from deepsvc_amd.modules import Conv2d
+    ops.set_precision("f16")
+    h = torch.float16
+    try:
+        torch.manual_seed(2)
+        conv = Conv2d(cin, cout, k, 1, k // 2).to(DEV)
+        x_clean = torch.randn((1, H, W, cin), device=DEV).to(h)
+        head = cout <= 3
+        odt = torch.float32 if head else h
+        kw = dict(act=1)
+        r_clean = torch.randn((1, H, W, cout), device=DEV) if head else None
+        if head:
+            kw["res1"] = ops.Act(r_clean)
+        before = ops.get_counter(counter)
+        ref = conv.run(ops.Act(x_clean), out_dtype=odt, **kw).buf.clone()
+        assert ops.get_counter(counter) == before + 1, f"{name}: the kernel under test did not take this launch"
+        if cin == 8:
+            x = ops.Act(x_clean)
+        else:
+            wide_in = torch.randn((1, H, W, cin + 32), device=DEV).to(h)
+            wide_in[..., 16:16 + cin] = x_clean
+            x = ops.Act(wide_in, 16, cin)
+        oc0 = 8 if odt == h else 4                     # 16-byte aligned slice start in either type
+        wide_out = torch.full((1, H, W, cout + 24), 7.0, device=DEV, dtype=odt)
+        if head:
+            wide_res = torch.randn((1, H, W, cout + 5), device=DEV)
+            wide_res[..., 2:2 + cout] = r_clean
+            kw["res1"] = ops.Act(wide_res, 2, cout)
+        out = conv.run(x, ops.Act(wide_out, oc0, cout), out_dtype=odt, **kw)
+        torch.cuda.synchronize()
+        assert ops.get_counter(counter) == before + 2, f"{name}: the kernel under test did not take the launch on views"
+        got = wide_out[..., oc0:oc0 + cout]
+        assert torch.equal(got, ref), f"{name}: differs from the run on plain tensors"
+        assert bool((wide_out[..., :oc0] == 7).all()) and bool((wide_out[..., oc0 + cout:] == 7).all()), f"{name}: wrote beside its output slice"
+    finally:
+        ops.set_precision("fp32")
+
+
 def test_pp_kernel_mixed_precision_residual_epilogue():
     """Option pp_mix (round 5): f16(x + r) of the two-group 3x3 kernel's residual variants as v_fma_mixlo_f16 / v_fma_mixhi_f16 (the f16
     residual enters the FMA directly, the fp32 sum is rounded ONCE to f16) instead of cvt + add + cvt_pk (rounded to fp32, then to f16).
