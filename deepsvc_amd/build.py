@@ -104,6 +104,13 @@ def build(force=False, verbose=False, variant=None, defines=()):
     FLAGS = globals()["FLAGS"] + list(defines)
     objs, relink = [], force or not os.path.exists(LIB)
     procs = []
+    # objects / reports of sources that are no longer part of the library (a removed kernel file) must not be linked, gated or counted
+    keep = {os.path.splitext(s)[0] for s in SOURCES}
+    for f in os.listdir(obj_dir):
+        stem = f.split(".")[0]
+        if stem not in keep and f.endswith((".o", ".usage.json", ".stores.json")):
+            os.remove(os.path.join(obj_dir, f))
+            relink = True
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
